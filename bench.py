@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the MI355X SpinRelax hot path (BASELINE.json metric:
+frame*vector*lag triples/s for the C(t) + R1/R2/NOE pipeline).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL backend)
+
+A "step" is one pass of the whole hot path over one synthetic trajectory shard that is already
+resident in HBM: pack -> C(t) -> rotation + spherical histogram -> multi-exponential fits with the
+model-order search -> J(omega)/R1/R2/NOE/rho, and for N > 1 the RCCL all-gather of the per-shard results
+(SURVEY.md section 8(e)).  Workload: BASELINE.json configs[2] (100 000 frames x 512 vectors, 2 048 lags,
+axisymmetric D, q_ext rotation + vecHistogram) PER GPU -- the configuration the north-star quotes its
+scaling on; weak scaling: every rank owns its own 512 vectors (rank r = vectors 512 r .. 512 r + 511
+of one synthetic trajectory).  `value` = exact triples of all ranks / wall time of a step.
+
+One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel (k_ct_palmer): 8 flop x exact triples per launch / mean launch time
+                (HIP events on the launch stream, inside the timed region) against the 157.3 TFLOP/s
+                FP32 vector peak (= the FP32 MFMA peak) of MI355X_MICROARCH.md; SURVEY.md section 8(d).
+  cpu_baseline  the reference's algorithm (per-lag float32 numpy einsum, calculate-Ct-from-traj.py:222-228,
+                restated in oracle/sr_oracle.py) timed on this host on a bounded sample (rank 0, N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector = FP32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', type=str, default='cfg3', choices=['cfg2', 'cfg3'])
+    ap.add_argument('--vectors', type=int, default=None, help='vectors per GPU (default: the config value)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-vectors', type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(vecs_sample, s):
+    """Reference-equivalent CPU path for C(t) on a bounded sample; returns the cpu_baseline object."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import sr_oracle as o
+    v4 = vecs_sample[: s['N']].reshape(s['R'], s['F'], -1, 3)
+    triples = o.exact_triples(s['R'], s['F'], v4.shape[2])
+    t0 = time.time()
+    o.calculate_Ct_Palmer(v4, dtype=np.float32)          # same numpy calls as the reference, float32, 1 thread
+    dt = time.time() - t0
+    out = dict(value=triples / dt, unit='triples/s', cores=1, kind='port',
+               sample='C(t) stage only: %d chunks x %d frames x %d vectors (%.3g exact triples) of the same '
+                      'trajectory, numpy float32 per-lag einsum as calculate-Ct-from-traj.py:222-228, %.1f s'
+                      % (s['R'], s['F'], v4.shape[2], triples, dt))
+    # the same algorithm as a multi-threaded C loop (oracle/ct_palmer_oracle.c), all host cores
+    try:
+        import ctypes
+        import subprocess
+        so = os.path.join(ROOT, 'oracle', 'libsr_oracle.so')
+        if not os.path.isfile(so):
+            subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'libsr_oracle.so'],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lib = ctypes.CDLL(so)
+        v4c = np.ascontiguousarray(v4, dtype=np.float32)
+        L = s['F'] // 2
+        Ct = np.empty((L, v4c.shape[2]), dtype=np.float32)
+        dCt = np.empty_like(Ct)
+        t0 = time.time()
+        lib.sr_oracle_ct_palmer_f32_stream(v4c.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(s['R']), ctypes.c_int64(s['F']),
+                                           ctypes.c_int64(v4c.shape[2]), Ct.ctypes.data_as(ctypes.c_void_p),
+                                           dCt.ctypes.data_as(ctypes.c_void_p))
+        dt2 = time.time() - t0
+        out['all_cores'] = dict(value=triples / dt2, cores=os.cpu_count(), kind='port (C + OpenMP, same per-lag streaming algorithm)')
+    except Exception as exc:                                 # the extra figure is optional
+        out['all_cores'] = dict(error=str(exc))
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from spinrelax_amd import synth
+    from spinrelax_amd.hip import Context
+    from spinrelax_amd.pipeline import DevicePipeline
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+
+    cfg = 3 if args.workload == 'cfg3' else 2
+    s = synth.config_shapes(cfg)
+    V = args.vectors or s['V']
+    aniso = synth.DANI if cfg == 3 else None
+    q = synth.Q_EXT if cfg == 3 else None
+    # ---- synthetic shard of this rank: generated on the host BEFORE the GPU is initialised (worker pool forks) ----
+    t0 = time.time()
+    vecs_host = synth.synth_vectors_parallel(s['frames'], V, s['seed'], v0=rank * V)
+    gen_s = time.time() - t0
+
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+    if args.gpus != world and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    vecs = torch.from_numpy(vecs_host).to(dev)           # resident in HBM before the timed region
+    stream = torch.cuda.Stream(device=dev)
+    ctx = Context(local)
+    ctx.set_stream(stream.cuda_stream)
+    triples = synth.exact_triples(s['R'], s['F'], V)
+
+    with torch.cuda.stream(stream):
+        pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], q_rot=q, Diso=synth.DISO, aniso=aniso,
+                              field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA)
+
+        def gather_results():
+            if world == 1:
+                return
+            for tns in (pipe.Ct, pipe.dCt, pipe.hist):
+                out = [torch.empty_like(tns) for _ in range(world)]
+                dist.all_gather(out, tns.contiguous())
+            r = torch.from_numpy(np.ascontiguousarray(pipe.relax_out)).to(dev)
+            out = [torch.empty_like(r) for _ in range(world)]
+            dist.all_gather(out, r)
+
+        def one_step(ev=None):
+            pipe.stage_pack(vecs)
+            if ev is not None:
+                ev[0].record(stream)
+            pipe.stage_ct()
+            if ev is not None:
+                ev[1].record(stream)
+            pipe.stage_hist()
+            if ev is not None:
+                ev[2].record(stream)
+            pipe.stage_fit()
+            pipe.stage_relax()
+            gather_results()
+
+        for _ in range(args.warmup):
+            one_step()
+        events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            one_step(events[k])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ct_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    hist_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = triples * world / (elapsed / args.steps)
+        achieved = 8.0 * triples / (ct_ms * 1e-3) / 1e12
+        best, _ = pipe.fit_best, None
+        res = {
+            'metric': 'frame-vector-lag triples/s, C(t) + fit + R1/R2/NOE pipeline',
+            'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 dot products / f64 accumulation (C(t)); f64 (histogram, fit, J(w), R1/R2/NOE)',
+            'data': 'synthetic',
+            'config': {'workload': 'BASELINE cfg%d per GPU: %d frames x %d vectors, %d chunks x %d frames, %d lags, '
+                                   '%s, fits 2/3/5/7/9 params, 1 field' % (cfg, s['frames'], V, s['R'], s['F'], s['L'],
+                                                                           'axisymmetric D + q_ext + 72x36 histogram' if cfg == 3 else 'isotropic D'),
+                       'vectors_per_gpu': V, 'exact_triples_per_gpu': triples, 'sharding': 'vectors (no data-path collective; all-gather of results)'},
+            'roofline': {'bound': 'valu-fp32 (non-MFMA vector FMA; FP32 MFMA peak is the same 157.3)', 'kernel': 'k_ct_palmer',
+                         'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS,
+                         'traffic': None, 'kernel_ms': ct_ms, 'flop_per_triple': 8,
+                         'streaming_equiv_GBps': 24.0 * triples / (ct_ms * 1e-3) / 1e9,
+                         'streaming_equiv_frac_of_hbm': 24.0 * triples / (ct_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            'stages_ms': {'ct_palmer': ct_ms, 'rotate_hist': hist_ms,
+                          'rotate_hist_GBps': 12.0 * s['N'] * V / (hist_ms * 1e-3) / 1e9},
+            'fit': {'residues': V, 'selected_orders': {str(pipe.listDoG[j]): int((best == j).sum()) for j in range(len(pipe.listDoG))},
+                    'unfitted': int((best < 0).sum())},
+            'setup': {'synth_s': gen_s},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            nvs = min(args.cpu_sample_vectors, V)
+            res['cpu_baseline'] = cpu_baseline(vecs_host[:, :nvs], s)
+        else:
+            res['cpu_baseline'] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

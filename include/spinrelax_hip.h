@@ -1,0 +1,159 @@
+/*
+ * spinrelax_hip.h -- C ABI of libspinrelax_hip.so: the MI355X (gfx950) implementation of SpinRelax's
+ * bond-vector autocorrelation -> spectral density -> R1/R2/NOE hot path.
+ *
+ * The reference (zharmad/SpinRelax) has no FFI for this path: its boundary is four CLI scripts,
+ * their file formats, a handful of Python functions and ONE native symbol, the numpy ufunc
+ * npufunc.Jomega (Jomega/Jomega.c:30-156).  Each entry point below names the reference
+ * function (file:line, relative to the reference root) whose work it replaces; INTEGRATION.md shows
+ * the ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, negative = error; text via sr_last_error();
+ *   - plain pointers and sizes only; "_dev" entry points take DEVICE pointers and enqueue work on the
+ *     context's stream without synchronising (outputs are valid after sr_sync or a stream sync);
+ *     entry points without "_dev" take HOST pointers, stage through the context's workspace and
+ *     block until the result is in the caller's buffer;
+ *   - one sr_ctx per GPU per thread; no internal locking; no callbacks or exceptions cross the ABI;
+ *   - there is no CPU fallback: without a gfx950 device sr_create fails.
+ */
+#ifndef SPINRELAX_HIP_H
+#define SPINRELAX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sr_ctx sr_ctx;
+
+#define SR_ABI_VERSION 1
+
+/* ---- context, memory, timing ------------------------------------------------------------- */
+int          sr_abi_version(void);
+const char  *sr_last_error(void);
+sr_ctx      *sr_create(int device);                 /* NULL on failure (see sr_last_error)        */
+void         sr_destroy(sr_ctx *);
+int          sr_set_stream(sr_ctx *, void *hip_stream);   /* hipStream_t; NULL = default stream  */
+int          sr_sync(sr_ctx *);
+int          sr_device_info(sr_ctx *, int *n_cu, int64_t *hbm_bytes, int *lds_per_cu, char *name, int name_len);
+void        *sr_malloc(sr_ctx *, size_t bytes);     /* device memory                              */
+int          sr_free(sr_ctx *, void *dev_ptr);
+int          sr_memcpy_h2d(sr_ctx *, void *dev_dst, const void *host_src, size_t bytes);
+int          sr_memcpy_d2h(sr_ctx *, void *host_dst, const void *dev_src, size_t bytes);
+int          sr_memset(sr_ctx *, void *dev_dst, int value, size_t bytes);
+/* HIP events on the context's stream (the stream the kernels are launched on). */
+int          sr_timer_start(sr_ctx *);
+int          sr_timer_stop_ms(sr_ctx *, float *elapsed_ms);     /* synchronises on the stop event */
+
+/* ---- kernel 0: frame-major -> per-vector planes -------------------------------------------
+ * Input is the layout the reference holds vectors in, (nframes, nvectors, 3) float32
+ * (obtain_XHvecs, calculate-Ct-from-traj.py:64-86).  Output "SoA": soa[(v*3 + c)*Npad + n] for the
+ * vector range [v0, v0+nV): the shard a GPU owns.  Npad >= N, Npad % 4 == 0. */
+int sr_pack_soa_f32_dev(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
+                        float *soa, int64_t Npad);
+
+/* ---- kernel 1: Palmer-chunked P2 autocorrelation ------------------------------------------
+ * Replaces calculate_Ct_Palmer (calculate-Ct-from-traj.py:200-238) after reformat_vecs_by_tau
+ * (:245-275).  Chunk r covers frames [chunk_start[r], chunk_start[r]+F) of the packed planes
+ * (chunk_start == NULL means r*F).  For delta = 1..L, L = F/2:
+ *     p[r,v]      = (1/(F-delta)) * sum_j ( 1.5 (u[r,j,v].u[r,j+delta,v])^2 - 0.5 )
+ *     Ct[d-1,v]   = mean_r p ;   dCt[d-1,v] = std_r(p, ddof=0) / (sqrt(R) - 1)
+ * Ct, dCt are (L, nV) float64, row-major -- the reference's (nDeltas, nResidues).
+ * mode 0: float32 dot products and short float32 partial sums folded into float64 (fast path);
+ * mode 1: every product and sum in float64 (validation path, ~10x slower).
+ * psum (optional, may be NULL): (nV, R, Lp) float64 raw sums  sum_j (u.u')^2, Lp = sr_ct_psum_stride(F). */
+int64_t sr_ct_psum_stride(int64_t F);
+int64_t sr_ct_max_frames_per_chunk(sr_ctx *);
+int sr_ct_palmer_f32_dev(sr_ctx *, const float *soa, int64_t Npad, int64_t R, int64_t F, int64_t nV,
+                         const int64_t *chunk_start_host, int mode,
+                         double *psum_ws, double *Ct, double *dCt);
+/* host-buffer form: vecs is (N, Vtot, 3) float32 on the host, N >= R*F when chunk_start is NULL. */
+int sr_ct_palmer_f32(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
+                     int64_t R, int64_t F, const int64_t *chunk_start_host, int mode,
+                     double *Ct, double *dCt);
+
+/* ---- kernel 2: quaternion rotation + Lambert-cylindrical histogram + mean vector + S2 ------
+ * Replaces rotate_vector_simd (transforms3d_supplement.py:270-296), xyz_to_rtp
+ * (general_maths.py:118-158), the per-bond np.histogramdd loop (calculate-Ct-from-traj.py:600-626),
+ * the mean vector (:579-583) and calculate_S2_by_outerProduct (:96-145) in one pass over the planes.
+ *   q           : 4 doubles (w,x,y,z), normalised inside like the reference; NULL = no rotation;
+ *   edges_phi   : nphi+1 doubles, edges_cos: ncos+1 doubles -- the numpy.linspace edges; binning is
+ *                 numpy's: searchsorted(edges, x, 'right')-1, last edge inclusive, outside/NaN dropped;
+ *   hist        : (nV, nphi, ncos) float64 counts (the dtype the reference stores);
+ *   vecsum      : (nV, 3) float64 sum over the first N frames of the rotated vectors (may be NULL);
+ *   outer       : (nBlocks, nV, 6) float64 sums of xx,yy,zz,xy,xz,yz per block of block_len frames
+ *                 (may be NULL; nBlocks = N_used / block_len). */
+int sr_rotate_hist_f32_dev(sr_ctx *, const float *soa, int64_t Npad, int64_t N, int64_t nV,
+                           const double *q_host, const double *edges_phi_host, int nphi,
+                           const double *edges_cos_host, int ncos,
+                           double *hist, double *vecsum, double *outer, int64_t block_len);
+int sr_rotate_hist_f32(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
+                       const double *q, const double *edges_phi, int nphi, const double *edges_cos, int ncos,
+                       double *hist, double *vecsum, double *outer, int64_t block_len);
+/* rotated vectors themselves, float64 (N, nV, 3) like the reference returns (for --vecDist output). */
+int sr_rotate_vectors_f32(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
+                          const double *q, double *out);
+
+/* ---- kernel 3b: multi-exponential C(t) model --------------------------------------------
+ * Model of curvefit_exponential (fitting_Ct_functions.py:419-427): params = [C_1..C_K, tau_1..tau_K
+ * (, S2)], P = 2K or 2K+1; even P: S2 = 1 - sum C.  resid = (model - C)/sigma (sigma may be NULL),
+ * jac[i,l,p] = d resid[i,l] / d param[i,p] (analytic).  All arrays row-major float64. */
+int sr_expfit_resjac_f64(sr_ctx *, const double *t /*[nRes,L]*/, const double *C, const double *sigma,
+                         const double *params /*[nRes,P]*/, int nRes, int L, int P,
+                         double *resid /*[nRes,L]*/, double *jac /*[nRes,L,P] or NULL*/);
+/* Batched bounded least-squares fit, one workgroup per residue, whole solve on the device
+ * (replaces the scipy curve_fit call of conduct_curve_fitting, fitting_Ct_functions.py:322-324:
+ * bounds 0 <= C,S2 <= 1, 0 <= tau <= tau_max).  p0 in / popt out (nRes,P); pcov (nRes,P,P) is the
+ * curve_fit covariance (J^T J)^-1 * 2 cost/(L-P); chisq = mean(resid_unweighted^2 / sigma)
+ * (calc_chiSq, :272-276); status per residue: >0 converged (1 gtol, 2 ftol, 3 xtol), 0 max iterations,
+ * <0 failure.  Host pointers. */
+int sr_expfit_lm_f64(sr_ctx *, const double *t, const double *C, const double *sigma, int nRes, int L, int P,
+                     const double *p0, double tau_max, int max_iter,
+                     double *popt, double *pcov, double *chisq, int *status, int *n_iter);
+/* device-pointer form; skip (nRes bytes, device, may be NULL): residues with skip[i] != 0 are left
+ * untouched (used by the host-side model-order search, which stops residues individually);
+ * max_iter < 0 selects the analytic Jacobian instead of scipy's 2-point differences. */
+int sr_expfit_lm_f64_dev(sr_ctx *, const double *t, const double *C, const double *sigma, int nRes, int L, int P,
+                         const double *p0, double tau_max, int max_iter, const unsigned char *skip,
+                         double *popt, double *pcov, double *chisq, int *status, int *n_iter);
+
+/* ---- kernel 3a: J(omega) and R1/R2/NOE/rho ----------------------------------------------
+ * sr_jomega_f64: elementwise x/(x*x+y*y), the double loop of Jomega/Jomega.c:49-66, evaluated on the
+ * GPU (host pointers; n elements, both inputs already broadcast by the caller). */
+int sr_jomega_f64(sr_ctx *, const double *x, const double *y, double *out, int64_t n);
+
+/* Batched relaxation.  Replaces _obtain_R1R2NOErho / _obtain_Jomega
+ * (calculate-relaxations-from-Ct.py:82-191) and the class API spinRelaxationR1/R2/NOE.eval
+ * (spectral_densities.py:820-907) for E "experiments" (field settings) at once.
+ *   model        0 direct transform (J_direct_transform, spectral_densities.py:2024-2033)
+ *                1 rigid sphere, D[0] = Diso (J_combine_isotropic_exp_decayN, :2038-2050)
+ *                2 symmetric top, D[0] = Dpar, D[1] = Dperp (J_combine_symmtop_exp_decayN, :2057-2077)
+ *   omega        (E,5): [0, wX, wH-wX, wH, wH+wX] in 1/time-unit
+ *   f_DD (E), f_CSA (E,nRes), time_fact (E), gamma_ratio (E) = gamma_H/gamma_X
+ *   S2 (nRes), C/tau (nRes,Kmax) with nComps (nRes) valid entries -- already zeta-scaled
+ *   binvecs (B,3) unit vectors shared by every residue (bin centres) or (nRes,3) when B == 0
+ *   weights (nRes,B) or NULL (uniform); a DEVICE pointer when weights_on_device != 0 (the histogram
+ *                kernel 2 left in HBM), otherwise a host pointer
+ *   noe_mode     0: NOE from the per-vector R1 (old API, :1706/:1722)
+ *                1: NOE from the vector-averaged R1 (new API, :881-892)
+ *   out          (E, nRes, 4, 2): {R1,R2,NOE,rho} x {weighted mean, weighted sigma}; sigma = 0 when B == 0
+ *   Jout         (E, nRes, 5, 2) weighted mean/sigma of J(omega) or NULL (the --Jomega output)
+ * Host pointers. */
+int sr_jomega_relax_f64(sr_ctx *, int model, const double *D, int E, const double *omega, const double *f_DD,
+                        const double *f_CSA, const double *time_fact, const double *gamma_ratio,
+                        int nRes, int Kmax, const double *S2, const double *C, const double *tau, const int *nComps,
+                        int B, const double *binvecs, const double *weights, int weights_on_device, int noe_mode,
+                        double *out, double *Jout);
+
+/* ---- small device utilities ---------------------------------------------------------------
+ * out[c*rows + r] = in[r*cols + c] (float64, device pointers): C(t) leaves kernel 1 as (lags, vectors)
+ * like the reference, the fit reads (residues, lags). */
+int sr_transpose_f64_dev(sr_ctx *, const double *in, int64_t rows, int64_t cols, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPINRELAX_HIP_H */

@@ -1,0 +1,95 @@
+"""
+ctypes binding of libspinrelax_hip.so (include/spinrelax_hip.h).
+
+There is deliberately NO CPU fallback: if the shared library is missing, cannot be loaded, or no
+gfx950 device is present, every compute entry point raises SpinRelaxHipError.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libspinrelax_hip.so')
+
+
+class SpinRelaxHipError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); mirrors include/spinrelax_hip.h one to one
+SIGNATURES = {
+    'sr_abi_version': (c_int, []),
+    'sr_last_error': (c_char_p, []),
+    'sr_create': (c_void_p, [c_int]),
+    'sr_destroy': (None, [c_void_p]),
+    'sr_set_stream': (c_int, [c_void_p, c_void_p]),
+    'sr_sync': (c_int, [c_void_p]),
+    'sr_device_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int64), POINTER(c_int), c_char_p, c_int]),
+    'sr_malloc': (c_void_p, [c_void_p, c_size_t]),
+    'sr_free': (c_int, [c_void_p, c_void_p]),
+    'sr_memcpy_h2d': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'sr_memcpy_d2h': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'sr_memset': (c_int, [c_void_p, c_void_p, c_int, c_size_t]),
+    'sr_timer_start': (c_int, [c_void_p]),
+    'sr_timer_stop_ms': (c_int, [c_void_p, POINTER(c_float)]),
+    'sr_pack_soa_f32_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64]),
+    'sr_ct_psum_stride': (c_int64, [c_int64]),
+    'sr_ct_max_frames_per_chunk': (c_int64, [c_void_p]),
+    'sr_ct_palmer_f32_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int,
+                                     c_void_p, c_void_p, c_void_p]),
+    'sr_ct_palmer_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                 c_void_p, c_int, c_void_p, c_void_p]),
+    'sr_rotate_hist_f32_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64]),
+    'sr_rotate_hist_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int,
+                                   c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64]),
+    'sr_rotate_vectors_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    'sr_expfit_resjac_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                     c_void_p, c_void_p]),
+    'sr_expfit_lm_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_double,
+                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'sr_expfit_lm_f64_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_double,
+                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'sr_transpose_f64_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'sr_jomega_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
+    'sr_jomega_relax_f64': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_int, c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and attach the signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise SpinRelaxHipError(
+            '%s not found: build it with `python -m spinrelax_amd.build` (needs hipcc). '
+            'spinrelax_amd has no CPU fallback.' % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise SpinRelaxHipError('cannot load %s: %s' % (LIB_PATH, exc))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise SpinRelaxHipError('%s does not export %s (stale build?)' % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sr_abi_version() != 1:
+        raise SpinRelaxHipError('ABI version mismatch: library %d, binding 1' % lib.sr_abi_version())
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().sr_last_error().decode('utf-8', 'replace')
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SpinRelaxHipError('%s failed (%d): %s' % (what, rc, last_error()))

@@ -1,0 +1,173 @@
+// sr_core.hip -- context, device memory, stream and HIP-event timing of libspinrelax_hip.so
+#include "sr_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void sr_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+void *sr_workspace(sr_ctx *ctx, int slot, size_t bytes)
+{
+    if (slot < 0 || slot >= SR_NSLOTS) { sr_set_error("bad workspace slot %d", slot); return nullptr; }
+    if (bytes == 0) bytes = 16;
+    if (ctx->slot_bytes[slot] >= bytes) return ctx->slot[slot];
+    if (ctx->slot[slot]) {
+        // make sure nothing enqueued on the stream still uses the old buffer
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->slot[slot]);
+        ctx->slot[slot] = nullptr;
+        ctx->slot_bytes[slot] = 0;
+    }
+    size_t want = bytes + bytes / 8;            // 12.5 % head-room so near-equal sizes do not realloc
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        sr_set_error("hipMalloc(%zu bytes) for workspace slot %d failed: %s", want, slot, hipGetErrorString(e));
+        return nullptr;
+    }
+    ctx->slot[slot] = p;
+    ctx->slot_bytes[slot] = want;
+    return p;
+}
+
+extern "C" {
+
+int sr_abi_version(void) { return SR_ABI_VERSION; }
+
+const char *sr_last_error(void) { return g_err; }
+
+sr_ctx *sr_create(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        sr_set_error("no HIP device available (%s); libspinrelax_hip has no CPU fallback",
+                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= n) { sr_set_error("device %d out of range (0..%d)", device, n - 1); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { sr_set_error("hipSetDevice(%d) failed", device); return nullptr; }
+    sr_ctx *ctx = new sr_ctx();
+    memset(ctx, 0, sizeof(*ctx));
+    ctx->device = device;
+    ctx->stream = nullptr;
+    if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) {
+        sr_set_error("hipGetDeviceProperties failed");
+        delete ctx;
+        return nullptr;
+    }
+    if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        sr_set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device, ctx->prop.gcnArchName);
+        delete ctx;
+        return nullptr;
+    }
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        sr_set_error("hipEventCreate failed");
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+void sr_destroy(sr_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < SR_NSLOTS; ++i)
+        if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+int sr_set_stream(sr_ctx *ctx, void *hip_stream)
+{
+    SR_CHECK_CTX(ctx);
+    ctx->stream = (hipStream_t)hip_stream;
+    return 0;
+}
+
+int sr_sync(sr_ctx *ctx)
+{
+    SR_CHECK_CTX(ctx);
+    SR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sr_device_info(sr_ctx *ctx, int *n_cu, int64_t *hbm_bytes, int *lds_per_cu, char *name, int name_len)
+{
+    SR_CHECK_CTX(ctx);
+    if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
+    if (lds_per_cu) *lds_per_cu = (int)ctx->prop.maxSharedMemoryPerMultiProcessor;
+    if (name && name_len > 0) {
+        snprintf(name, (size_t)name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    }
+    return 0;
+}
+
+void *sr_malloc(sr_ctx *ctx, size_t bytes)
+{
+    if (!ctx) { sr_set_error("null sr_ctx"); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { sr_set_error("hipSetDevice failed"); return nullptr; }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) { sr_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+
+int sr_free(sr_ctx *ctx, void *p)
+{
+    SR_CHECK_CTX(ctx);
+    if (p) SR_HIP(hipFree(p));
+    return 0;
+}
+
+int sr_memcpy_h2d(sr_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    SR_CHECK_CTX(ctx);
+    SR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sr_memcpy_d2h(sr_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    SR_CHECK_CTX(ctx);
+    SR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sr_memset(sr_ctx *ctx, void *dst, int value, size_t bytes)
+{
+    SR_CHECK_CTX(ctx);
+    SR_HIP(hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return 0;
+}
+
+int sr_timer_start(sr_ctx *ctx)
+{
+    SR_CHECK_CTX(ctx);
+    SR_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return 0;
+}
+
+int sr_timer_stop_ms(sr_ctx *ctx, float *ms)
+{
+    SR_CHECK_CTX(ctx);
+    SR_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    SR_HIP(hipEventSynchronize(ctx->ev1));
+    float t = 0.f;
+    SR_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+    if (ms) *ms = t;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,411 @@
+// sr_ct.hip -- kernel 0 (frame-major -> per-vector planes) and kernel 1 (Palmer-chunked P2
+// autocorrelation) for gfx950.
+//
+// Reference semantics: calculate_Ct_Palmer, calculate-Ct-from-traj.py:200-238 (see include/spinrelax_hip.h).
+//
+// Kernel 1 design (DESIGN.md section "C(t) kernel"):
+//   * one workgroup stages ONE (chunk r, vector v) time series of F frames into LDS as three float
+//     planes (x, y, z) -- 48 KB at F = 4096, so three workgroups share a CU's 160 KB;
+//   * the (j, lag) plane is cut into lag blocks of 128 lags; a wave owns a lag block, its 64 lanes
+//     are 4 j-strips x 16 lag-lanes, each lag-lane owns 8 consecutive lags.  Per step a lane loads
+//     8 a-values and 16 b-values per component with ds_read_b128 and issues 8x8x4 = 256 FMAs
+//     (3 for u(j).u(j+lag), 1 for the square-accumulate): 18 LDS b128 reads per 256 FMAs;
+//   * LDS layout is "chunk-parity split": 16-byte chunk c of a plane lives in half (c & 1) at slot
+//     (c >> 1), so that lag-lanes whose windows start 8 floats (2 chunks) apart read consecutive
+//     16-byte slots -> conflict-free ds_read_b128;
+//   * partial sums: float32, 4 independent accumulators per lag, at most 16 terms each, folded into
+//     float64 every 8 steps; strips are combined with two float64 wave shuffles; no atomics;
+//   * lags that do not fill a 128-lag block (for F = 4096 only lag 2048) and the validation mode run
+//     through a simple float64 path in the same launch.
+#include "sr_internal.h"
+
+namespace {
+
+constexpr int kLagBlock = 128;     // lags per wave pass
+constexpr int kLagsPerLane = 8;
+constexpr int kJT = 8;             // j values per lane step
+constexpr int kFlush = 8;          // lane steps between float32 -> float64 folds
+constexpr float kCenter = 8.0f;    // accumulators start at -kCenter so the <=16 terms (each in [0,1]) keep
+                                   // the running float32 sum near zero: halves the accumulation rounding
+constexpr int kPad = 176;          // zero padding behind the series (max overshoot of a window: 167)
+
+__host__ __device__ inline int64_t ct_Fp(int64_t F)
+{
+    // smallest Fp >= F + kPad with Fp % 64 == 32 (so the two parity halves are 16 banks apart)
+    int64_t x = F + kPad;
+    int64_t base = (x / 64) * 64 + 32;
+    if (base < x) base += 64;
+    return base;
+}
+
+__device__ __forceinline__ int lds_pos(int e, int H)
+{
+    const int c = e >> 2;
+    return (c & 1) * H + ((c >> 1) << 2) + (e & 3);
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel 0: (N, Vtot, 3) float32 -> planes soa[(v*3+c)*Npad + n], zero for n in [N, Npad)
+// ------------------------------------------------------------------------------------------
+constexpr int kPackFrames = 64;
+constexpr int kPackVecs = 32;
+
+__global__ __launch_bounds__(256) void k_pack_soa(const float *__restrict__ vecs, int64_t N, int64_t Vtot,
+                                                  int64_t v0, int64_t nV, float *__restrict__ soa, int64_t Npad)
+{
+    __shared__ float tile[kPackVecs * 3][kPackFrames + 1];
+    const int64_t n0 = (int64_t)blockIdx.x * kPackFrames;
+    const int64_t vb = (int64_t)blockIdx.y * kPackVecs;
+    const int nvec = (int)min((int64_t)kPackVecs, nV - vb);
+    const int row = nvec * 3;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < kPackFrames * row; idx += 256) {
+        const int n = idx / row, k = idx - n * row;
+        const int64_t fr = n0 + n;
+        float val = 0.f;
+        if (fr < N) val = vecs[(fr * Vtot + v0 + vb) * 3 + k];
+        tile[k][n] = val;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kPackFrames * row; idx += 256) {
+        const int k = idx / kPackFrames, n = idx - k * kPackFrames;
+        const int64_t fr = n0 + n;
+        if (fr < Npad) soa[(vb * 3 + k) * Npad + fr] = tile[k][n];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel 1
+// ------------------------------------------------------------------------------------------
+struct CtArgs {
+    const float *soa;
+    int64_t Npad;
+    const int64_t *chunk_start;   // device, may be null
+    double *psum;                 // (nV, R, Lp)
+    int R, F, Fp, L, Lp, nslab, mode;
+};
+
+template <int W>
+__global__ __launch_bounds__(W * 64) void k_ct_palmer(CtArgs a)
+{
+    extern __shared__ __align__(16) float lds[];
+    const int Fp = a.Fp, H = Fp >> 1, F = a.F;
+    float *X = lds, *Y = lds + Fp, *Z = lds + 2 * Fp;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int series = blockIdx.x / a.nslab;
+    const int slab = blockIdx.x - series * a.nslab;
+    const int v = series / a.R;
+    const int r = series - v * a.R;
+
+    // ---- stage the series (coalesced dword loads; zero padding behind frame F) ----
+    {
+        const int64_t start = a.chunk_start ? a.chunk_start[r] : (int64_t)r * F;
+        const float *px = a.soa + ((int64_t)v * 3 + 0) * a.Npad + start;
+        const float *py = px + a.Npad;
+        const float *pz = py + a.Npad;
+        for (int e = tid; e < Fp; e += W * 64) {
+            const int p = lds_pos(e, H);
+            const bool in = e < F;
+            X[p] = in ? px[e] : 0.f;
+            Y[p] = in ? py[e] : 0.f;
+            Z[p] = in ? pz[e] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    const int NW = a.nslab * W;            // workers (waves) per series
+    const int wid = slab * W + wave;
+    double *out = a.psum + ((int64_t)v * a.R + r) * a.Lp;
+    const int nb = (a.mode == 0) ? (a.L + 1) / kLagBlock : 0;
+
+    // ---- fast path: full lag blocks, serpentine assignment balances the (F - lag) work ----
+    const int g = lane >> 4;               // j strip 0..3
+    const int l16 = lane & 15;             // lag lane 0..15
+    for (int i = 0; i * NW < nb; ++i) {
+        const int k = (i & 1) ? i * NW + (NW - 1 - wid) : i * NW + wid;
+        if (k >= nb) continue;
+        const int dw = k * kLagBlock;
+        const int nj = F - dw;
+        const int S = (((nj + 3) >> 2) + 7) & ~7;          // strip length, multiple of 8
+        const int iters = S >> 3;
+        int a_off = (g * S) >> 1;                           // float offset inside a parity half
+        int b_off = (g * S + dw + kLagsPerLane * l16) >> 1;
+        double acc64[kLagsPerLane];
+#pragma unroll
+        for (int d = 0; d < kLagsPerLane; ++d) acc64[d] = 0.0;
+
+        for (int it0 = 0; it0 < iters; it0 += kFlush) {
+            float acc[kLagsPerLane][4];
+#pragma unroll
+            for (int d = 0; d < kLagsPerLane; ++d)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[d][q] = -kCenter;
+            const int n = min(kFlush, iters - it0);
+            for (int ii = 0; ii < n; ++ii) {
+                float ax[kJT], ay[kJT], az[kJT], bx[16], by[16], bz[16];
+                {
+                    const float4 t0 = *reinterpret_cast<const float4 *>(X + a_off);
+                    const float4 t1 = *reinterpret_cast<const float4 *>(X + H + a_off);
+                    ax[0] = t0.x; ax[1] = t0.y; ax[2] = t0.z; ax[3] = t0.w;
+                    ax[4] = t1.x; ax[5] = t1.y; ax[6] = t1.z; ax[7] = t1.w;
+                    const float4 u0 = *reinterpret_cast<const float4 *>(Y + a_off);
+                    const float4 u1 = *reinterpret_cast<const float4 *>(Y + H + a_off);
+                    ay[0] = u0.x; ay[1] = u0.y; ay[2] = u0.z; ay[3] = u0.w;
+                    ay[4] = u1.x; ay[5] = u1.y; ay[6] = u1.z; ay[7] = u1.w;
+                    const float4 w0 = *reinterpret_cast<const float4 *>(Z + a_off);
+                    const float4 w1 = *reinterpret_cast<const float4 *>(Z + H + a_off);
+                    az[0] = w0.x; az[1] = w0.y; az[2] = w0.z; az[3] = w0.w;
+                    az[4] = w1.x; az[5] = w1.y; az[6] = w1.z; az[7] = w1.w;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int off = b_off + (c >> 1) * 4 + (c & 1) * H;
+                    const float4 t = *reinterpret_cast<const float4 *>(X + off);
+                    bx[4 * c] = t.x; bx[4 * c + 1] = t.y; bx[4 * c + 2] = t.z; bx[4 * c + 3] = t.w;
+                    const float4 u = *reinterpret_cast<const float4 *>(Y + off);
+                    by[4 * c] = u.x; by[4 * c + 1] = u.y; by[4 * c + 2] = u.z; by[4 * c + 3] = u.w;
+                    const float4 w = *reinterpret_cast<const float4 *>(Z + off);
+                    bz[4 * c] = w.x; bz[4 * c + 1] = w.y; bz[4 * c + 2] = w.z; bz[4 * c + 3] = w.w;
+                }
+#pragma unroll
+                for (int jj = 0; jj < kJT; ++jj) {
+#pragma unroll
+                    for (int d = 0; d < kLagsPerLane; ++d) {
+                        float dot = ax[jj] * bx[jj + d];
+                        dot = fmaf(ay[jj], by[jj + d], dot);
+                        dot = fmaf(az[jj], bz[jj + d], dot);
+                        acc[d][jj & 3] = fmaf(dot, dot, acc[d][jj & 3]);
+                    }
+                }
+                a_off += 4;
+                b_off += 4;
+            }
+#pragma unroll
+            for (int d = 0; d < kLagsPerLane; ++d) {
+                const float s = (acc[d][0] + acc[d][1]) + (acc[d][2] + acc[d][3]);
+                acc64[d] += (double)s + 4.0 * (double)kCenter;
+            }
+        }
+        // combine the 4 j strips (lanes l16, l16+16, l16+32, l16+48)
+#pragma unroll
+        for (int d = 0; d < kLagsPerLane; ++d) {
+            double s = acc64[d];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            acc64[d] = s;
+        }
+        if (g == 0) {
+            double *o = out + dw + kLagsPerLane * l16;
+#pragma unroll
+            for (int d = 0; d < kLagsPerLane; ++d) o[d] = acc64[d];
+        }
+    }
+
+    // ---- float64 path: remaining lags (and every lag in validation mode) ----
+    {
+        int lo = nb * kLagBlock;
+        if (lo < 1) lo = 1;
+        for (int d = lo + wid; d <= a.L; d += NW) {
+            double s = 0.0;
+            for (int j = lane; j + d < F; j += 64) {
+                const int pa = lds_pos(j, H), pb = lds_pos(j + d, H);
+                const double x = (double)X[pa] * (double)X[pb] + (double)Y[pa] * (double)Y[pb] +
+                                 (double)Z[pa] * (double)Z[pb];
+                s += x * x;
+            }
+            s = wave_sum_f64(s);
+            if (lane == 0) out[d] = s;
+        }
+    }
+}
+
+// mean / std over the R replicate chunks, calculate-Ct-from-traj.py:226-228
+__global__ __launch_bounds__(256) void k_ct_finalize(const double *__restrict__ psum, int R, int F, int L, int Lp,
+                                                     int64_t nV, double *__restrict__ Ct, double *__restrict__ dCt)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nV * L) return;
+    const int64_t v = idx / L;
+    const int d = (int)(idx - v * L) + 1;
+    const double *p = psum + v * R * Lp + d;
+    const double n = (double)(F - d);
+    double m = 0.0;
+    for (int r = 0; r < R; ++r) m += 1.5 * (p[(int64_t)r * Lp] / n) - 0.5;
+    m /= (double)R;
+    double s = 0.0;
+    for (int r = 0; r < R; ++r) {
+        const double e = (1.5 * (p[(int64_t)r * Lp] / n) - 0.5) - m;
+        s += e * e;
+    }
+    const int64_t o = (int64_t)(d - 1) * nV + v;
+    Ct[o] = m;
+    dCt[o] = sqrt(s / (double)R) / (sqrt((double)R) - 1.0);
+}
+
+__global__ __launch_bounds__(256) void k_transpose_f64(const double *__restrict__ in, int64_t rows, int64_t cols,
+                                                       double *__restrict__ out)
+{
+    __shared__ double tile[32][33];
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < rows && c0 + tx < cols) tile[k][tx] = in[(r0 + k) * cols + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < cols && r0 + tx < rows) out[(c0 + k) * rows + r0 + tx] = tile[tx][k];
+}
+
+template <int W>
+int launch_ct(sr_ctx *ctx, const CtArgs &a, int64_t nblocks, size_t lds_bytes)
+{
+    static size_t configured = 0;
+    if (lds_bytes > configured) {
+        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ct_palmer<W>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        configured = lds_bytes;
+    }
+    hipLaunchKernelGGL(k_ct_palmer<W>, dim3((unsigned)nblocks), dim3(W * 64), lds_bytes, ctx->stream, a);
+    SR_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sr_transpose_f64_dev(sr_ctx *ctx, const double *in, int64_t rows, int64_t cols, double *out)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(in && out && rows > 0 && cols > 0, -2, "sr_transpose_f64_dev: bad arguments");
+    const int64_t gx = (cols + 31) / 32, gy = (rows + 31) / 32;
+    SR_REQUIRE(gy <= 65535, -3, "sr_transpose_f64_dev: too many rows");
+    hipLaunchKernelGGL(k_transpose_f64, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ctx->stream, in, rows, cols, out);
+    SR_HIP(hipGetLastError());
+    return 0;
+}
+
+int64_t sr_ct_psum_stride(int64_t F) { return sr_round_up(F / 2 + 1 + kLagBlock, 8); }
+
+int64_t sr_ct_max_frames_per_chunk(sr_ctx *ctx)
+{
+    if (!ctx) return -1;
+    const int64_t lds = (int64_t)sr_lds_limit(ctx);
+    int64_t F = lds / 12 - kPad - 64;
+    return F > 0 ? F : 0;
+}
+
+int sr_pack_soa_f32_dev(sr_ctx *ctx, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
+                        float *soa, int64_t Npad)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(vecs && soa, -2, "sr_pack_soa_f32_dev: null pointer");
+    SR_REQUIRE(N > 0 && Vtot > 0 && nV > 0 && v0 >= 0 && v0 + nV <= Vtot, -3,
+               "sr_pack_soa_f32_dev: bad shape N=%lld Vtot=%lld v0=%lld nV=%lld", (long long)N, (long long)Vtot,
+               (long long)v0, (long long)nV);
+    SR_REQUIRE(Npad >= N && Npad % 4 == 0, -3, "sr_pack_soa_f32_dev: Npad=%lld must be >= N and a multiple of 4",
+               (long long)Npad);
+    const int64_t gx = (Npad + kPackFrames - 1) / kPackFrames;
+    const int64_t gy = (nV + kPackVecs - 1) / kPackVecs;
+    SR_REQUIRE(gy <= 65535, -3, "sr_pack_soa_f32_dev: too many vectors in one call (%lld)", (long long)nV);
+    hipLaunchKernelGGL(k_pack_soa, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ctx->stream, vecs, N, Vtot, v0, nV,
+                       soa, Npad);
+    SR_HIP(hipGetLastError());
+    return 0;
+}
+
+int sr_ct_palmer_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t R, int64_t F, int64_t nV,
+                         const int64_t *chunk_start_host, int mode, double *psum_ws, double *Ct, double *dCt)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(soa && Ct && dCt, -2, "sr_ct_palmer_f32_dev: null pointer");
+    SR_REQUIRE(R >= 1 && F >= 2 && nV >= 1, -3, "sr_ct_palmer_f32_dev: bad shape R=%lld F=%lld nV=%lld", (long long)R,
+               (long long)F, (long long)nV);
+    SR_REQUIRE(mode == 0 || mode == 1, -3, "sr_ct_palmer_f32_dev: mode must be 0 or 1");
+    const int64_t Fp = ct_Fp(F);
+    const size_t lds_bytes = (size_t)Fp * 3 * sizeof(float);
+    SR_REQUIRE(lds_bytes <= sr_lds_limit(ctx), -4,
+               "sr_ct_palmer_f32_dev: F=%lld frames per chunk need %zu B of LDS (> %zu); max F is %lld",
+               (long long)F, lds_bytes, sr_lds_limit(ctx),
+               (long long)sr_ct_max_frames_per_chunk(ctx));
+    SR_REQUIRE(R * nV < (int64_t)1 << 30, -3, "sr_ct_palmer_f32_dev: too many series");
+    const int64_t L = F / 2;
+    const int64_t Lp = sr_ct_psum_stride(F);
+    if (chunk_start_host) {
+        for (int64_t r = 0; r < R; ++r)
+            SR_REQUIRE(chunk_start_host[r] >= 0 && chunk_start_host[r] + F <= Npad, -3,
+                       "sr_ct_palmer_f32_dev: chunk %lld start %lld out of range", (long long)r,
+                       (long long)chunk_start_host[r]);
+    } else {
+        SR_REQUIRE(R * F <= Npad, -3, "sr_ct_palmer_f32_dev: R*F=%lld exceeds Npad=%lld", (long long)(R * F),
+                   (long long)Npad);
+    }
+    double *psum = psum_ws;
+    if (!psum) {
+        psum = (double *)sr_workspace(ctx, SR_WS_PSUM, (size_t)(nV * R * Lp) * sizeof(double));
+        if (!psum) return -5;
+    }
+    int64_t *cs_dev = nullptr;
+    if (chunk_start_host) {
+        cs_dev = (int64_t *)sr_workspace(ctx, SR_WS_MISC, (size_t)R * sizeof(int64_t));
+        if (!cs_dev) return -5;
+        SR_HIP(hipMemcpyAsync(cs_dev, chunk_start_host, (size_t)R * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    CtArgs a;
+    a.soa = soa; a.Npad = Npad; a.chunk_start = cs_dev; a.psum = psum;
+    a.R = (int)R; a.F = (int)F; a.Fp = (int)Fp; a.L = (int)L; a.Lp = (int)Lp; a.mode = mode;
+    const int nb = mode == 0 ? (int)((L + 1) / kLagBlock) : 0;
+    const int64_t series = R * nV;
+    int rc;
+    if (mode == 1) {
+        a.nslab = 1;
+        rc = launch_ct<4>(ctx, a, series, lds_bytes);
+    } else if (nb >= 16) {
+        a.nslab = nb >= 64 ? nb / 32 : 1;            // about 4-8 lag blocks per wave
+        rc = launch_ct<4>(ctx, a, series * a.nslab, lds_bytes);
+    } else {
+        a.nslab = nb > 0 ? nb : 1;                   // one wave per workgroup, one lag block per wave
+        rc = launch_ct<1>(ctx, a, series * a.nslab, lds_bytes);
+    }
+    if (rc) return rc;
+    const int64_t tot = nV * L;
+    hipLaunchKernelGGL(k_ct_finalize, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, psum, (int)R,
+                       (int)F, (int)L, (int)Lp, nV, Ct, dCt);
+    SR_HIP(hipGetLastError());
+    return 0;
+}
+
+int sr_ct_palmer_f32(sr_ctx *ctx, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV, int64_t R,
+                     int64_t F, const int64_t *chunk_start_host, int mode, double *Ct, double *dCt)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(vecs && Ct && dCt, -2, "sr_ct_palmer_f32: null pointer");
+    SR_REQUIRE(N > 0 && Vtot > 0 && nV > 0 && v0 >= 0 && v0 + nV <= Vtot, -3, "sr_ct_palmer_f32: bad shape");
+    const int64_t Npad = sr_round_up(N, 64);
+    const size_t in_bytes = (size_t)N * Vtot * 3 * sizeof(float);
+    float *dvecs = (float *)sr_workspace(ctx, SR_WS_VECS, in_bytes);
+    float *soa = (float *)sr_workspace(ctx, SR_WS_SOA, (size_t)nV * 3 * Npad * sizeof(float));
+    const int64_t L = F / 2;
+    double *dCt_d = (double *)sr_workspace(ctx, SR_WS_OUT1, (size_t)(L * nV) * sizeof(double));
+    double *Ct_d = (double *)sr_workspace(ctx, SR_WS_OUT0, (size_t)(L * nV) * sizeof(double));
+    if (!dvecs || !soa || !Ct_d || !dCt_d) return -5;
+    SR_HIP(hipMemcpyAsync(dvecs, vecs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    int rc = sr_pack_soa_f32_dev(ctx, dvecs, N, Vtot, v0, nV, soa, Npad);
+    if (rc) return rc;
+    rc = sr_ct_palmer_f32_dev(ctx, soa, Npad, R, F, nV, chunk_start_host, mode, nullptr, Ct_d, dCt_d);
+    if (rc) return rc;
+    SR_HIP(hipMemcpyAsync(Ct, Ct_d, (size_t)(L * nV) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(dCt, dCt_d, (size_t)(L * nV) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

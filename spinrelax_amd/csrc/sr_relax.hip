@@ -1,0 +1,283 @@
+// sr_relax.hip -- kernel 3a: batched spectral densities J(omega) and R1 / R2 / NOE / rho.
+//
+// Reference semantics:
+//   Jomega ufunc  x/(x*x+y*y)                      Jomega/Jomega.c:49-66
+//   _do_Jsum                                        spectral_densities.py:1961-1972
+//   D_/A_coefficients_symmtop                       spectral_densities.py:1874-1906
+//   J_direct_transform / J_combine_isotropic_exp_decayN / J_combine_symmtop_exp_decayN
+//                                                   spectral_densities.py:2024-2077
+//   get_relax_from_J(_simd), get_rho_from_J(_simd)  spectral_densities.py:1680-1786   (noe_mode 0)
+//   spinRelaxationR1/R2/NOE.eval                    spectral_densities.py:820-907     (noe_mode 1)
+//   weighted_average_stdev                          general_maths.py:100-110
+//   _obtain_R1R2NOErho, _obtain_Jomega              calculate-relaxations-from-Ct.py:82-191
+//
+// One workgroup per (residue, experiment).  For the symmetric top the bin-centre vectors are the same
+// for every residue, and J(bin, w) = sum_j A_j(bin) * G[j][w] with the 3x5 table
+// G[j][w] = S2*Jomega(D_j, w) + sum_k C_k*Jomega(D_j + 1/tau_k, w) independent of the bin, so a bin
+// costs 15 FMAs.  Weighted mean and weighted sigma over the bins use two passes (mean first), like
+// numpy.average followed by average((x-mean)^2).
+#include "sr_internal.h"
+
+namespace {
+
+constexpr int kMaxK = 8;
+constexpr int kNQ = 10;      // R1, R2, NOE(old), rho, Nterm(6J4-J2), J0..J4
+
+struct RelaxArgs {
+    int model, E, nRes, Kmax, B, noe_mode;
+    double D0, D1;
+    const double *omega, *f_DD, *f_CSA, *time_fact, *gamma_ratio;
+    const double *S2, *C, *tau;
+    const int *nComps;
+    const double *binvecs, *weights;
+    double *out, *Jout;
+};
+
+__device__ __forceinline__ double jomega(double x, double y) { return x / (x * x + y * y); }
+
+__device__ __forceinline__ void quantities(const double *J, double fDD, double fCSA, double tf, double gr, double *q)
+{
+    const double J0 = J[0], J1 = J[1], J2 = J[2], J3 = J[3], J4 = J[4];
+    const double R1 = tf * (fDD * (J2 + 3 * J1 + 6 * J4) + fCSA * J1);
+    const double R2 = tf * (0.5 * fDD * (4 * J0 + J2 + 3 * J1 + 6 * J4 + 6 * J3) + 1.0 / 6.0 * fCSA * (4 * J0 + 3 * J1));
+    const double Nt = 6 * J4 - J2;
+    q[0] = R1;
+    q[1] = R2;
+    q[2] = 1.0 + tf * gr / R1 * fDD * Nt;
+    q[3] = J1 / J0;
+    q[4] = Nt;
+    q[5] = J0; q[6] = J1; q[7] = J2; q[8] = J3; q[9] = J4;
+}
+
+__device__ void block_sum(double *vals, int n, double *red, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int k = 0; k < n; ++k) {
+        double t = vals[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+        if (lane == 0) red[wave * 16 + k] = t;
+    }
+    __syncthreads();
+    for (int k = 0; k < n; ++k) vals[k] = ((red[k] + red[16 + k]) + red[32 + k]) + red[48 + k];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_relax(RelaxArgs a)
+{
+    __shared__ double G[3][5];
+    __shared__ double red[64];
+    const int i = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
+    const double *om = a.omega + e * 5;
+    const double fDD = a.f_DD[e], fCSA = a.f_CSA[(int64_t)e * a.nRes + i], tf = a.time_fact[e], gr = a.gamma_ratio[e];
+    const double S2 = a.S2[i];
+    const double *C = a.C + (int64_t)i * a.Kmax, *tau = a.tau + (int64_t)i * a.Kmax;
+    const int K = a.nComps[i];
+    const bool prolate = a.D0 > a.D1;
+    double *out = a.out + ((int64_t)e * a.nRes + i) * 8;
+    double *Jout = a.Jout ? a.Jout + ((int64_t)e * a.nRes + i) * 10 : nullptr;
+
+    if (tid < 15) {
+        const int j = tid / 5, w = tid - j * 5;
+        double g = 0.0;
+        if (a.model == 2) {
+            const double Dpar = a.D0, Dperp = a.D1;
+            const double DJ = j == 0 ? 5 * Dperp + Dpar : (j == 1 ? 2 * Dperp + 4 * Dpar : 6 * Dperp);
+            g = S2 * jomega(DJ, om[w]);
+            for (int k = 0; k < K; ++k) g += C[k] * jomega(DJ + 1. / tau[k], om[w]);
+        } else if (j == 0) {
+            if (a.model == 1) {
+                const double tg = 1.0 / (6.0 * a.D0);
+                g = S2 * tg / (1. + (om[w] * tg) * (om[w] * tg));
+                for (int k = 0; k < K; ++k) {
+                    const double kk = (1.0 / tg) + (1.0 / tau[k]);
+                    g += C[k] * kk / (kk * kk + om[w] * om[w]);
+                }
+            } else {
+                for (int k = 0; k < K; ++k) g += C[k] * tau[k] / (1 + (tau[k] * om[w]) * (tau[k] * om[w]));
+            }
+        }
+        G[j][w] = g;
+    }
+    __syncthreads();
+
+    if (a.model != 2 || a.B == 0) {
+        // one J per residue: no distribution, sigma = 0
+        if (tid == 0) {
+            double J[5], q[kNQ];
+            if (a.model == 2) {
+                const double *v = a.binvecs + (int64_t)i * 3;
+                const double z = prolate ? v[2] : v[0];
+                const double z2 = z * z, w1 = 1 - z2;
+                const double A0 = 3.0 * (z2 * w1), A1 = 0.75 * (w1 * w1), A2 = 0.25 * ((3 * z2 - 1) * (3 * z2 - 1));
+                for (int w = 0; w < 5; ++w) J[w] = A0 * G[0][w] + A1 * G[1][w] + A2 * G[2][w];
+            } else {
+                for (int w = 0; w < 5; ++w) J[w] = G[0][w];
+            }
+            quantities(J, fDD, fCSA, tf, gr, q);
+            for (int k = 0; k < 4; ++k) { out[2 * k] = q[k]; out[2 * k + 1] = 0.0; }
+            if (Jout) for (int w = 0; w < 5; ++w) { Jout[2 * w] = J[w]; Jout[2 * w + 1] = 0.0; }
+        }
+        return;
+    }
+
+    const double *wgt = a.weights ? a.weights + (int64_t)i * a.B : nullptr;
+    double mean[kNQ];
+    double wsum;
+    {   // pass 1: weighted means
+        double s[kNQ + 1];
+        for (int k = 0; k <= kNQ; ++k) s[k] = 0.0;
+        for (int b = tid; b < a.B; b += 256) {
+            const double w_ = wgt ? wgt[b] : 1.0;
+            const double *v = a.binvecs + (int64_t)b * 3;
+            const double z = prolate ? v[2] : v[0];
+            const double z2 = z * z, w1 = 1 - z2;
+            const double A0 = 3.0 * (z2 * w1), A1 = 0.75 * (w1 * w1), A2 = 0.25 * ((3 * z2 - 1) * (3 * z2 - 1));
+            double J[5], q[kNQ];
+            for (int w = 0; w < 5; ++w) J[w] = A0 * G[0][w] + A1 * G[1][w] + A2 * G[2][w];
+            quantities(J, fDD, fCSA, tf, gr, q);
+            for (int k = 0; k < kNQ; ++k) s[k] += w_ * q[k];
+            s[kNQ] += w_;
+        }
+        block_sum(s, kNQ + 1, red, tid);
+        wsum = s[kNQ];
+        for (int k = 0; k < kNQ; ++k) mean[k] = s[k] / wsum;
+    }
+    double var[kNQ];
+    {   // pass 2: weighted variance about the mean
+        double s[kNQ];
+        for (int k = 0; k < kNQ; ++k) s[k] = 0.0;
+        for (int b = tid; b < a.B; b += 256) {
+            const double w_ = wgt ? wgt[b] : 1.0;
+            const double *v = a.binvecs + (int64_t)b * 3;
+            const double z = prolate ? v[2] : v[0];
+            const double z2 = z * z, w1 = 1 - z2;
+            const double A0 = 3.0 * (z2 * w1), A1 = 0.75 * (w1 * w1), A2 = 0.25 * ((3 * z2 - 1) * (3 * z2 - 1));
+            double J[5], q[kNQ];
+            for (int w = 0; w < 5; ++w) J[w] = A0 * G[0][w] + A1 * G[1][w] + A2 * G[2][w];
+            quantities(J, fDD, fCSA, tf, gr, q);
+            for (int k = 0; k < kNQ; ++k) { const double d = q[k] - mean[k]; s[k] += w_ * (d * d); }
+        }
+        block_sum(s, kNQ, red, tid);
+        for (int k = 0; k < kNQ; ++k) var[k] = s[k] / wsum;
+    }
+    if (tid == 0) {
+        out[0] = mean[0]; out[1] = sqrt(var[0]);
+        out[2] = mean[1]; out[3] = sqrt(var[1]);
+        if (a.noe_mode == 0) {
+            out[4] = mean[2]; out[5] = sqrt(var[2]);
+        } else {
+            // NOE_b = 1 + c*N_b with c = tf*gr*fDD/<R1>: mean and sigma of an affine map of N
+            const double c = tf * gr / mean[0] * fDD;
+            out[4] = 1.0 + c * mean[4];
+            out[5] = fabs(c) * sqrt(var[4]);
+        }
+        out[6] = mean[3]; out[7] = sqrt(var[3]);
+        if (Jout) for (int w = 0; w < 5; ++w) { Jout[2 * w] = mean[5 + w]; Jout[2 * w + 1] = sqrt(var[5 + w]); }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_jomega(const double *__restrict__ x, const double *__restrict__ y,
+                                                double *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = jomega(x[i], y[i]);
+}
+
+template <typename T>
+T *upload(sr_ctx *ctx, int slot, const T *host, size_t count, int *rc)
+{
+    T *d = (T *)sr_workspace(ctx, slot, count * sizeof(T));
+    if (!d) { *rc = -5; return nullptr; }
+    hipError_t e = hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { sr_set_error("upload: %s", hipGetErrorString(e)); *rc = -100 - (int)e; return nullptr; }
+    return d;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sr_jomega_f64(sr_ctx *ctx, const double *x, const double *y, double *out, int64_t n)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(x && y && out && n >= 0, -2, "sr_jomega_f64: bad arguments");
+    if (n == 0) return 0;
+    int rc = 0;
+    double *dx = upload(ctx, SR_WS_IN0, x, (size_t)n, &rc);
+    double *dy = upload(ctx, SR_WS_IN1, y, (size_t)n, &rc);
+    double *dout = (double *)sr_workspace(ctx, SR_WS_OUT0, (size_t)n * sizeof(double));
+    if (rc || !dx || !dy || !dout) return rc ? rc : -5;
+    hipLaunchKernelGGL(k_jomega, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dx, dy, dout, n);
+    SR_HIP(hipGetLastError());
+    SR_HIP(hipMemcpyAsync(out, dout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sr_jomega_relax_f64(sr_ctx *ctx, int model, const double *D, int E, const double *omega, const double *f_DD,
+                        const double *f_CSA, const double *time_fact, const double *gamma_ratio, int nRes, int Kmax,
+                        const double *S2, const double *C, const double *tau, const int *nComps, int B,
+                        const double *binvecs, const double *weights, int weights_on_device, int noe_mode, double *out,
+                        double *Jout)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(model >= 0 && model <= 2, -3, "sr_jomega_relax_f64: model must be 0, 1 or 2");
+    SR_REQUIRE(E >= 1 && nRes >= 1 && Kmax >= 1 && Kmax <= kMaxK && B >= 0, -3, "sr_jomega_relax_f64: bad sizes");
+    SR_REQUIRE(E <= 65535, -3, "sr_jomega_relax_f64: too many experiments");
+    SR_REQUIRE(omega && f_DD && f_CSA && time_fact && gamma_ratio && S2 && C && tau && nComps && out, -2,
+               "sr_jomega_relax_f64: null pointer");
+    SR_REQUIRE(model == 0 || D, -2, "sr_jomega_relax_f64: D required");
+    SR_REQUIRE(model != 2 || binvecs, -2, "sr_jomega_relax_f64: symmetric top needs vectors");
+    SR_REQUIRE(noe_mode == 0 || noe_mode == 1, -3, "sr_jomega_relax_f64: noe_mode must be 0 or 1");
+    for (int i = 0; i < nRes; ++i)
+        SR_REQUIRE(nComps[i] >= 0 && nComps[i] <= Kmax, -3, "sr_jomega_relax_f64: nComps[%d]=%d out of range", i, nComps[i]);
+    // pack every input into one staging buffer
+    const size_t nE = (size_t)E, nR = (size_t)nRes;
+    const size_t cnt = nE * 5 + nE + nE * nR + nE + nE + nR + 2 * nR * Kmax +
+                       (model == 2 ? (B > 0 ? (size_t)B * 3 : nR * 3) : 0) +
+                       ((B > 0 && weights && !weights_on_device) ? nR * B : 0);
+    double *stage = (double *)sr_workspace(ctx, SR_WS_IN0, cnt * sizeof(double));
+    int *ncomp_d = (int *)sr_workspace(ctx, SR_WS_IN1, nR * sizeof(int));
+    double *out_d = (double *)sr_workspace(ctx, SR_WS_OUT0, nE * nR * 8 * sizeof(double));
+    double *J_d = Jout ? (double *)sr_workspace(ctx, SR_WS_OUT1, nE * nR * 10 * sizeof(double)) : nullptr;
+    if (!stage || !ncomp_d || !out_d || (Jout && !J_d)) return -5;
+    RelaxArgs a;
+    a.model = model; a.E = E; a.nRes = nRes; a.Kmax = Kmax; a.B = (model == 2) ? B : 0; a.noe_mode = noe_mode;
+    a.D0 = D ? D[0] : 0.0;
+    a.D1 = (D && model == 2) ? D[1] : 0.0;
+    double *p = stage;
+    auto put = [&](const double *src, size_t n) -> const double * {
+        hipError_t e = hipMemcpyAsync(p, src, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return nullptr;
+        const double *r = p;
+        p += n;
+        return r;
+    };
+    a.omega = put(omega, nE * 5);
+    a.f_DD = put(f_DD, nE);
+    a.f_CSA = put(f_CSA, nE * nR);
+    a.time_fact = put(time_fact, nE);
+    a.gamma_ratio = put(gamma_ratio, nE);
+    a.S2 = put(S2, nR);
+    a.C = put(C, nR * Kmax);
+    a.tau = put(tau, nR * Kmax);
+    a.binvecs = nullptr;
+    a.weights = nullptr;
+    if (model == 2) a.binvecs = put(binvecs, B > 0 ? (size_t)B * 3 : nR * 3);
+    if (model == 2 && B > 0 && weights) a.weights = weights_on_device ? weights : put(weights, nR * B);
+    SR_REQUIRE(a.omega && a.f_DD && a.f_CSA && a.time_fact && a.gamma_ratio && a.S2 && a.C && a.tau, -6,
+               "sr_jomega_relax_f64: host to device copy failed");
+    SR_HIP(hipMemcpyAsync(ncomp_d, nComps, nR * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    a.nComps = ncomp_d;
+    a.out = out_d;
+    a.Jout = J_d;
+    hipLaunchKernelGGL(k_relax, dim3((unsigned)nRes, (unsigned)E), dim3(256), 0, ctx->stream, a);
+    SR_HIP(hipGetLastError());
+    SR_HIP(hipMemcpyAsync(out, out_d, nE * nR * 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (Jout) SR_HIP(hipMemcpyAsync(Jout, J_d, nE * nR * 10 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

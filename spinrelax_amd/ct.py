@@ -1,0 +1,130 @@
+"""
+Host-side mirror of the C(t) / vector-distribution functions of the reference's
+calculate-Ct-from-traj.py, with the same names, argument meaning and error behaviour, computing on the
+MI355X through libspinrelax_hip.so.  There is no CPU compute path here: index arithmetic and
+formatting only; the arithmetic of the hot loops runs in the HIP kernels.
+"""
+import sys
+
+import numpy as np
+
+from . import hip
+
+
+def _ctx(ctx):
+    return ctx if ctx is not None else hip.default_context()
+
+
+def calculate_dt(dt, tau):
+    """calculate-Ct-from-traj.py:240-243: the lag axis (arange(int(0.5*tau/dt)) + 1) * dt."""
+    nPts = int(0.5 * tau / dt)
+    return (np.arange(nPts) + 1.0) * dt
+
+
+def concat_with_chunk_starts(vec_list, F):
+    """Index form of reformat_vecs_by_tau (calculate-Ct-from-traj.py:245-275): instead of copying the
+    used frames into a (R, F, V, 3) array, return the concatenation of the files, the start frame of
+    each of the R chunks and R.  The tail of every file that does not fill a chunk is skipped."""
+    starts = []
+    off = 0
+    for v in vec_list:
+        n = v.shape[0]
+        for c in range(n // F):
+            starts.append(off + c * F)
+        off += n
+    cat = vec_list[0] if len(vec_list) == 1 else np.concatenate(vec_list, axis=0)
+    return np.ascontiguousarray(cat, dtype=np.float32), np.array(starts, dtype=np.int64), len(starts)
+
+
+def reformat_vecs_by_tau(vecs, dt, tau):
+    """calculate-Ct-from-traj.py:245-275, same signature and prints: list of (frames, bonds, 3) arrays ->
+    (nchunk, frames_per_chunk, bonds, 3).  Kept for callers that want the 4-D array; the GPU path itself
+    uses concat_with_chunk_starts and never materialises it."""
+    nFiles = len(vecs)
+    nFramesPerChunk = int(tau / dt)
+    print("    ...debug: Using %i frames per chunk based on tau/dt (%g/%g)." % (nFramesPerChunk, tau, dt))
+    kept = []
+    for i in range(nFiles):
+        nFrames = vecs[i].shape[0]
+        used = int(nFrames / nFramesPerChunk) * nFramesPerChunk
+        print("    ...Source %i divided into %i chunks. Usage rate: %g %%" % (i, used / nFramesPerChunk, 100.0 * used / nFrames))
+        kept.append(vecs[i][0:used, ...])
+    out = np.concatenate(kept, axis=0)
+    nTot = out.shape[0]
+    print("    ...Done. vecs reformatted into %i chunks." % (nTot / nFramesPerChunk))
+    return out.reshape((int(nTot / nFramesPerChunk), nFramesPerChunk, out.shape[-2], out.shape[-1]))
+
+
+def calculate_Ct_Palmer(vecs, ctx=None, mode=0, v0=0, nV=None):
+    """calculate-Ct-from-traj.py:200-238.  vecs (nReplicates, nFrames, nResidues, 3) -> Ct, dCt of shape
+    (nDeltas, nResidues), float64 (the reference returns the dtype of vecs; the values here are the
+    float64 evaluation, see DESIGN.md "precision")."""
+    sh = vecs.shape
+    print("= = = Debug of calculate_Ct_Palmer confirming the dimensions of vecs:", sh)
+    if len(sh) != 4:
+        print("= = = ERROR: The input vectors to calculate_Ct_Palmer is not of the expected 4-dimensional form! ", sh,
+              file=sys.stderr)
+        sys.exit(1)
+    if sh[1] < 50:
+        print("= = = WARNING: there are less than 50 frames per block of memory-time!", file=sys.stderr)
+    R, F, V = sh[0], sh[1], sh[2]
+    flat = np.ascontiguousarray(vecs, dtype=np.float32).reshape(R * F, V, 3)
+    return _ctx(ctx).ct_palmer(flat, R, F, v0=v0, nV=nV, mode=mode)
+
+
+def calculate_Ct_from_files(vec_list, dt, tau, ctx=None, mode=0, v0=0, nV=None):
+    """reformat_vecs_by_tau + calculate_Ct_Palmer without the intermediate copy."""
+    F = int(tau / dt)
+    cat, starts, R = concat_with_chunk_starts(vec_list, F)
+    if R < 1:
+        print("= = = ERROR: no trajectory holds a full block of memory time tau!", file=sys.stderr)
+        sys.exit(1)
+    return _ctx(ctx).ct_palmer(cat, R, F, v0=v0, nV=nV, chunk_start=starts, mode=mode)
+
+
+def lambert_edges(histBinX=72):
+    """The bin edges numpy.histogramdd builds at calculate-Ct-from-traj.py:618 for
+    bins=(histBinX, int(histBinX/2)), range=((-pi,pi),(-1,1))."""
+    histBinY = int(histBinX / 2)
+    return [np.linspace(-np.pi, np.pi, histBinX + 1), np.linspace(-1.0, 1.0, histBinY + 1)]
+
+
+def vector_distribution(vecs, q_rot=None, histBinX=72, delta_t=-1, tau_memory=-1, ctx=None, v0=0, nV=None):
+    """One pass replacing calculate-Ct-from-traj.py:541-646 for the Histogram storage mode:
+    rotation into the PAF (rotate_vector_simd), mean vector (:579-583), Lambert-cylindrical histogram
+    (:585-626) and calculate_S2_by_outerProduct (:96-145).
+
+    vecs (N, V, 3) float32 (the 3-D array after the 4-D -> 3-D reshape at :535-536).
+    Returns dict(hist (V,X,Y) float64, edges [X+1, Y+1], avgvec (V,3), S2 (V,2) or (V,))."""
+    vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+    N = vecs.shape[0]
+    edges = lambert_edges(histBinX)
+    if delta_t < 0 or tau_memory < 0:
+        Fb = 0
+    else:
+        Fb = int(tau_memory / delta_t)
+    hist, vecsum, outer = _ctx(ctx).rotate_hist(vecs, q_rot, edges[0], edges[1], v0=v0, nV=nV, block_len=Fb)
+    mean = vecsum / N
+    avgvec = mean / np.sqrt((mean ** 2).sum(-1))[..., np.newaxis]
+    return dict(hist=hist, edges=edges, avgvec=avgvec, S2=S2_from_outer_sums(outer, Fb if Fb else N, blocked=bool(Fb)))
+
+
+def S2_from_outer_sums(outer, frames_per_block, blocked=True):
+    """calculate_S2_by_outerProduct (calculate-Ct-from-traj.py:125-142) from per-block sums of
+    xx,yy,zz,xy,xz,yz: S2 = 1.5*sum_ij <u_i u_j>^2 - 0.5; with blocks: mean and std/(sqrt(nBlocks)-1)."""
+    m = outer / frames_per_block
+    s = 1.5 * (m[..., 0] ** 2 + m[..., 1] ** 2 + m[..., 2] ** 2
+               + 2.0 * (m[..., 3] ** 2 + m[..., 4] ** 2 + m[..., 5] ** 2)) - 0.5
+    if not blocked:
+        return s[0]
+    nBlocks = s.shape[0]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return np.stack((np.mean(s, axis=0), np.std(s, axis=0) / (np.sqrt(nBlocks) - 1.0)), axis=-1)
+
+
+def rotate_vector_simd(v, q, ctx=None):
+    """transforms3d_supplement.py:270-296 for v (N, V, 3) float32 and one quaternion q (4,): float64 result."""
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    shp = v.shape
+    out = _ctx(ctx).rotate_vectors(v.reshape(-1, 1, 3) if v.ndim == 2 else v, q)
+    return out.reshape(shp)

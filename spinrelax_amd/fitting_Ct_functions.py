@@ -1,0 +1,544 @@
+"""
+Host-side mirror of the reference's fitting_Ct_functions.py: the containers for fitted
+autocorrelation models (same class / method / attribute names, same `_fittedCt.dat` text format) and
+the model-order search of optimised_curve_fitting.  Every least-squares solve runs on the GPU
+(sr_expfit_lm_f64: batched trust-region-reflective fit, one wave per residue); this module holds the
+host logic around it: initial guesses, bounds, quality flags and the accept/reject sequence, all
+restated in the reference's operation order including its quirks.
+
+Reference: fitting_Ct_functions.py:12-481.
+"""
+import sys
+from collections import OrderedDict
+
+import numpy as np
+
+from . import hip
+
+GREEK = np.array(['a', 'b', 'g', 'd', 'e', 'z', 'h'])      # fitting_Ct_functions.py:136
+
+
+def _ctx(ctx):
+    return ctx if ctx is not None else hip.default_context()
+
+
+# ---------------------------------------------------------------------------------------------------
+# pure host logic (unit-tested without a GPU)
+# ---------------------------------------------------------------------------------------------------
+def split_nparams(nParams):
+    """set_nParams, fitting_Ct_functions.py:376-382 -> (nComps, bS2Fast)."""
+    return int(nParams / 2), (nParams % 2 == 1)
+
+
+def initial_guess(DeltaT, Decay, nParams, nSample=10):
+    """initialise_for_fit_advanced, fitting_Ct_functions.py:359-374.  Returns the p0 list in the order
+    get_params_as_list produces ([C..., tau..., (S2)]) plus the (C list, S2) the later quality check uses."""
+    K, free = split_nparams(nParams)
+    tau = np.logspace(np.log10(np.mean(DeltaT[1:] - DeltaT[:-1])), np.log10(DeltaT[-1] * 2.0), K + 2)[1:-1]
+    avgBeg = np.mean(Decay[:nSample])
+    avgEnd = np.mean(Decay[-nSample:])
+    C = [np.fabs(avgBeg - avgEnd) / K] * K
+    S2 = avgEnd if free else 1.0 - np.mean(C)
+    p0 = list(C) + list(tau) + ([S2] if free else [])
+    return np.array(p0, dtype=float), C, S2
+
+
+def quality_flags(ok, popt, dParam, C0, S2_0, bS2Fast):
+    """The three flags of conduct_curve_fitting (fitting_Ct_functions.py:320-338).  Quirk kept: the
+    "sum > 1" test runs before the optimum is stored, i.e. on the INITIAL guess (C0, S2_0), with S2
+    overwritten by 1 - sum(C0) when it is not a free parameter (:330-331)."""
+    if not ok:
+        return [False, True, True]
+    q = [True, True, True]
+    with np.errstate(invalid='ignore'):
+        if np.any(dParam > popt):
+            q[1] = False
+    S2 = S2_0 if bS2Fast else 1.0 - np.sum(C0)
+    if S2 + np.sum(C0) > 1.0:
+        q[2] = False
+    return q
+
+
+class OrderSearch:
+    """State machine of optimised_curve_fitting (fitting_Ct_functions.py:278-304) for ONE residue, fed one
+    model order at a time so that many residues can advance in lock-step over batched GPU fits."""
+
+    def __init__(self, chiSqThreshold=0.5):
+        self.thr = chiSqThreshold
+        self.first = True
+        self.best = None          # dict of the accepted fit
+        self.last = None          # last fit attempted (what the reference leaves in `self` on total failure)
+        self.done = False
+
+    def feed(self, fit):
+        """fit: dict(chiSq, quality, ...).  Returns True while further orders should be tried."""
+        if self.done:
+            return False
+        self.last = fit
+        if self.first:
+            if np.all(fit['quality']):
+                self.best = fit
+                self.first = False
+            return True
+        if not np.all(fit['quality']):
+            self.done = True
+            return False
+        if fit['chiSq'] >= self.best['chiSq'] * self.thr:
+            self.done = True
+            return False
+        self.best = fit
+        return True
+
+    def result(self):
+        return self.best
+
+
+# ---------------------------------------------------------------------------------------------------
+# containers
+# ---------------------------------------------------------------------------------------------------
+class autoCorrelationModel:
+    """One residue's C(t) = S2 + sum_k C_k exp(-t/tau_k); see fitting_Ct_functions.py:128-416."""
+    dictGreek = GREEK
+
+    def __init__(self, name='Fit', listC=[], listTau=[], S2=None, bS2Fast=False, bSort=True):
+        self.name = name
+        self.tau = np.array(listTau, dtype=float)
+        self.C = np.array(listC, dtype=float)
+        self.bS2Fast = bS2Fast
+        self.S2 = S2
+        self.nComps = len(self.C)
+        self.nParams = len(self.C) + len(self.tau) + (1 if bS2Fast else 0)
+        self.bHasFit = False
+        self.zeta = 1.0
+        if bS2Fast and self.S2 is None:
+            print("= = = ERROR: S2 must be given in fitPatam initialisation is bS2Fast is set to True!")
+            sys.exit(1)
+        if self.S2 is None:
+            self.S2 = 1.0 - np.sum(self.C)
+        self.check_consistency()
+        if self.nComps > 1 and bSort:
+            self.sort_components()
+
+    def check_consistency(self):
+        if self.nComps < 1:
+            return
+        if len(self.C) != len(self.tau):
+            print("= = = ERROR: transient components in fitParam initialisation do not have matching number of parameters!")
+            sys.exit(1)
+        if not self.bS2Fast:
+            if not np.all(np.isclose(self.S2 + np.sum(self.C), 1.0, rtol=1e-6)):
+                print("= = = ERROR: Contribution of components in fitParam initialisation do not sum sufficeintly close to 1.00!")
+                sys.exit(1)
+
+    def set_nParams(self, n):
+        self.nParams = n
+        self.nComps, self.bS2Fast = split_nparams(n)
+
+    def calc_S2Fast(self):
+        return 1.0 - self.S2 - np.sum(self.C) if self.bS2Fast else 0.0
+
+    def sort_components(self):
+        inds = np.argsort(self.tau)
+        self.tau = self.tau[inds]
+        self.C = self.C[inds]
+        if self.bHasFit:
+            self.dtau = self.dtau[inds]
+            self.dC = self.dC[inds]
+
+    def set_zeta(self, zeta):
+        self.zeta = zeta
+
+    def get_zeta(self):
+        return self.zeta
+
+    def get_params_as_list(self):
+        return list(self.C) + list(self.tau) + ([self.S2] if self.bS2Fast else [])
+
+    def get_uncertainties_as_list(self):
+        return list(self.dC) + list(self.dtau) + ([self.dS2] if self.bS2Fast else [])
+
+    def eval(self, DeltaT):
+        """fitting_Ct_functions.py:266-270 (host evaluation for the exported model curve)."""
+        return self.zeta * (self.S2 + np.sum(self.C[:, np.newaxis] * np.exp(-1.0 * DeltaT[np.newaxis, :] / self.tau[:, np.newaxis]), axis=0))
+
+    def calc_chiSq(self, DeltaT, Decay, dDecay=None):
+        """fitting_Ct_functions.py:272-276: sigma, not sigma^2, in the denominator."""
+        if dDecay is None:
+            return np.mean(np.square(self.eval(DeltaT) - Decay))
+        return np.mean(np.square(self.eval(DeltaT) - Decay) / dDecay)
+
+    def _load_fit(self, fit):
+        """Install a fit dict produced by fit_batch (already component-sorted)."""
+        self.set_nParams(fit['nParams'])
+        self.C = np.array(fit['C'], dtype=float)
+        self.tau = np.array(fit['tau'], dtype=float)
+        self.S2 = fit['S2']
+        self.dC = np.array(fit['dC'], dtype=float)
+        self.dtau = np.array(fit['dtau'], dtype=float)
+        self.dS2 = fit['dS2']
+        self.chiSq = fit['chiSq']
+        self.bHasFit = True
+
+    def conduct_curve_fitting(self, DeltaT, Decay, dDecay=None, bReInitialise=False, fp=sys.stdout, ctx=None):
+        """fitting_Ct_functions.py:306-345 for the current nParams (GPU solve, batch of one)."""
+        fit = fit_batch(np.asarray(DeltaT)[None], np.asarray(Decay)[None], None if dDecay is None else np.asarray(dDecay)[None],
+                        self.nParams, ctx=ctx)[0]
+        if not fit['ok']:
+            print("= = = WARNING, curve fitting of %s with %i params failed!" % (self.name, self.nParams), file=fp)
+            return np.inf, fit['quality']
+        if not fit['quality'][1]:
+            print("= = = WARNING, curve fitting of %s with %i params indicates overfitting." % (self.name, self.nParams), file=fp)
+        if not fit['quality'][2]:
+            print("= = = WARNING, curve fitting of %s with %i params returns sum>1." % (self.name, self.nParams), file=fp)
+        self._load_fit(fit)
+        return self.chiSq, fit['quality']
+
+    def optimised_curve_fitting(self, DeltaT, Decay, dDecay=None, listDoG=[2, 3, 5, 7, 9], chiSqThreshold=0.5, fp=sys.stdout,
+                                ctx=None):
+        """fitting_Ct_functions.py:278-304 for one residue (batch of one on the GPU)."""
+        res = optimised_curve_fitting_batch([self.name], np.asarray(DeltaT)[None], np.asarray(Decay)[None],
+                                            None if dDecay is None else np.asarray(dDecay)[None], listDoG, chiSqThreshold,
+                                            fp=fp, ctx=ctx)[0]
+        if res is not None:
+            self._load_fit(res)
+            return self.chiSq
+        return np.inf
+
+    def report(self, style='stdout', fp=sys.stdout):
+        """fitting_Ct_functions.py:224-264; the 'xmgrace' style is the header block of _fittedCt.dat."""
+        g = autoCorrelationModel.dictGreek
+        if style == 'stdout':
+            print("Name: %s" % self.name, file=fp)
+            if self.bHasFit:
+                print('  chi-Square: %g ' % self.chiSq, file=fp)
+            if self.bS2Fast:
+                print("  S2_fast: %g" % self.calc_S2Fast(), file=fp)
+            for i in range(self.nComps):
+                if self.bHasFit:
+                    print("  component %s, const.: %g +- %g" % (g[i], self.C[i], self.dC[i]), file=fp)
+                    print("  component %s, tau: %g +- %g" % (g[i], self.tau[i], self.dtau[i]), file=fp)
+                else:
+                    print("  component %s, const.: %g " % (g[i], self.C[i]), file=fp)
+                    print("  component %s, tau: %g " % (g[i], self.tau[i]), file=fp)
+            if self.bHasFit:
+                print("  S2_0: %g +- %g" % (self.S2, self.dS2), file=fp)
+            else:
+                print("  S2_0: %g" % self.S2, file=fp)
+        elif style == 'xmgrace':
+            print('# Residue: %s ' % self.name, file=fp)
+            if self.bHasFit:
+                print('# Chi-Square: %g ' % self.chiSq, file=fp)
+                if self.bS2Fast:
+                    print('# Param S2_fast: %g +- 0.0' % self.calc_S2Fast(), file=fp)
+                    print('# Param S2_0: %g +- %g' % (self.S2, self.dS2), file=fp)
+                else:
+                    print('# Param S2_0: %g +- 0.0' % self.S2, file=fp)
+                for i in range(self.nComps):
+                    print('# Param C_%s: %g +- %g' % (g[i], self.C[i], self.dC[i]), file=fp)
+                    print('# Param tau_%s: %g +- %g' % (g[i], self.tau[i], self.dtau[i]), file=fp)
+            else:
+                if self.bS2Fast:
+                    print('# Param S2_fast: %g' % self.calc_S2Fast(), file=fp)
+                print('# Param S2_0: %g' % self.S2, file=fp)
+                for i in range(self.nComps):
+                    print('# Param C_%s: %g' % (g[i], self.C[i]), file=fp)
+                    print('# Param tau_%s: %g' % (g[i], self.tau[i]), file=fp)
+        else:
+            print("= = = ERROR: fitParam.report() does not recognise the style argument! Choices are: stdout, xmgrace",
+                  file=sys.stderr)
+
+
+class autoCorrelations:
+    """Set of models plus their target curves; see fitting_Ct_functions.py:12-126."""
+
+    def __init__(self):
+        self.nModels = 0
+        self.model = OrderedDict()
+        self.nTargets = 0
+        self.DeltaT = OrderedDict()
+        self.Decay = OrderedDict()
+        self.dDecay = OrderedDict()
+
+    def get_names(self):
+        return np.array([k for k in self.model.keys()])
+
+    def get_params_as_list(self):
+        keys = self.model.keys()
+        return ([self.model[k].S2 for k in keys], [self.model[k].C for k in keys], [self.model[k].tau for k in keys],
+                [self.model[k].calc_S2Fast() for k in keys])
+
+    def get_params_as_arrays(self, Kmax=None):
+        """Padded arrays for the batched GPU kernels: S2 (n,), C (n,Kmax), tau (n,Kmax), nComps (n,)."""
+        n = self.nModels
+        K = np.array([m.nComps for m in self.model.values()], dtype=np.int32)
+        Kmax = max(int(K.max()) if n else 1, 1) if Kmax is None else Kmax
+        C = np.zeros((n, Kmax))
+        tau = np.ones((n, Kmax))
+        S2 = np.zeros(n)
+        for i, m in enumerate(self.model.values()):
+            C[i, :K[i]] = m.C
+            tau[i, :K[i]] = m.tau
+            S2[i] = m.S2
+        return S2, C, tau, K
+
+    def set_zeta(self, zeta):
+        for m in self.model.values():
+            m.set_zeta(zeta)
+
+    def get_zeta(self):
+        for m in self.model.values():
+            return m.get_zeta()
+
+    def add_model(self, key, name=None, listC=[], listTau=[], S2=None, bS2Fast=False, bSort=True):
+        self.model[key] = autoCorrelationModel(key if name is None else name, listC, listTau, S2, bS2Fast, bSort)
+        self.nModels = len(self.model)
+        return self.model[key]
+
+    def get_nth_model(self, n):
+        return self.model[self.get_names()[n]]
+
+    def add_target(self, key, DeltaT, Decay, dDecay):
+        self.DeltaT[key] = DeltaT
+        self.Decay[key] = Decay
+        self.dDecay[key] = dDecay
+        self.nTargets = len(self.DeltaT)
+
+    def import_target_array(self, keys, DeltaT, Decay, dDecay=None):
+        for i, k in enumerate(keys):
+            self.add_target(k, DeltaT[i], Decay[i], None if dDecay is None else dDecay[i])
+
+    def report(self):
+        print("Number of C(t) models loaded:", self.nModels)
+        print("Number of targets loaded:", self.nTargets)
+
+    def fit_all(self, listDoG=[2, 3, 5, 7, 9], chiSqThreshold=0.5, nc=-1, bUseSFast=True, fp=sys.stdout, ctx=None):
+        """The per-residue loop of calculate-fitted-Ct.py:161-178, batched: every residue advances through
+        the model orders together, each order being ONE GPU launch over the residues still searching."""
+        keys = list(self.DeltaT.keys())
+        t = np.array([self.DeltaT[k] for k in keys], dtype=float)
+        y = np.array([self.Decay[k] for k in keys], dtype=float)
+        dy = None if self.dDecay[keys[0]] is None else np.array([self.dDecay[k] for k in keys], dtype=float)
+        if nc == -1:
+            results = optimised_curve_fitting_batch(keys, t, y, dy, listDoG, chiSqThreshold, fp=fp, ctx=ctx)
+        else:
+            nP = 2 * nc + 1 if bUseSFast else 2 * nc
+            results = [f if f['ok'] else None for f in fit_batch(t, y, dy, nP, ctx=ctx)]
+        for k, res in zip(keys, results):
+            obj = self.add_model(k)
+            if res is not None:
+                obj._load_fit(res)
+        return results
+
+    def export(self, fileName, style='xmgrace'):
+        """fitting_Ct_functions.py:107-126: header block, fitted curve, raw curve per residue."""
+        with open(fileName, 'w') as fp:
+            s = 0
+            for k, m in self.model.items():
+                m.report(style='xmgrace', fp=fp)
+                dt = self.DeltaT[k]
+                Ct = self.Decay[k]
+                ymodel = m.eval(dt)
+                print("@s%d legend \"Res %d\"" % (s, m.name), file=fp)
+                for j in range(len(ymodel)):
+                    print("%8g %8g" % (dt[j], ymodel[j]), file=fp)
+                print('&', file=fp)
+                for j in range(len(ymodel)):
+                    print("%8g %8g" % (dt[j], Ct[j]), file=fp)
+                print('&', file=fp)
+                s += 2
+
+
+# ---------------------------------------------------------------------------------------------------
+# GPU-backed batched fitting
+# ---------------------------------------------------------------------------------------------------
+def initial_guess_batch(t, y, nParams, nSample=10):
+    """Vectorised initial_guess for (n, L) arrays: identical floating-point results to the per-residue
+    function (same numpy reductions over the same contiguous runs).  Returns p0 (n, P), C0 (n, K), S2_0 (n,)."""
+    n = y.shape[0]
+    K, free = split_nparams(nParams)
+    if n > 1 and np.all(t == t[0]):
+        tau1 = np.logspace(np.log10(np.mean(t[0, 1:] - t[0, :-1])), np.log10(t[0, -1] * 2.0), K + 2)[1:-1]
+        tau = np.broadcast_to(tau1, (n, K))
+    else:
+        tau = np.array([np.logspace(np.log10(np.mean(t[i, 1:] - t[i, :-1])), np.log10(t[i, -1] * 2.0), K + 2)[1:-1]
+                        for i in range(n)]).reshape(n, K)
+    avgBeg = np.mean(y[:, :nSample], axis=1)
+    avgEnd = np.mean(y[:, -nSample:], axis=1)
+    C0 = np.repeat((np.fabs(avgBeg - avgEnd) / K)[:, None], K, axis=1)
+    S2_0 = avgEnd if free else 1.0 - np.mean(C0, axis=1)
+    p0 = np.concatenate([C0, tau] + ([S2_0[:, None]] if free else []), axis=1)
+    return np.ascontiguousarray(p0), C0, S2_0
+
+
+def host_runner(t, y, dy, ctx=None):
+    """Runner over host arrays: runner(nParams, p0, idx) -> popt, dP, chi, status for the residues idx."""
+    def run(nParams, p0, idx):
+        tmax = t[idx, -1]
+        popt = np.empty((idx.size, nParams))
+        dP = np.empty((idx.size, nParams))
+        chi = np.empty(idx.size)
+        status = np.empty(idx.size, dtype=np.int32)
+        for tm in np.unique(tmax):                       # tau bound = 10 * t_max (fitting_Ct_functions.py:324)
+            sel = np.flatnonzero(tmax == tm)
+            sub = idx[sel]
+            po, pc, ch, st, _ = _ctx(ctx).expfit(t[sub], y[sub], None if dy is None else dy[sub], p0[sel], tm * 10)
+            popt[sel] = po
+            with np.errstate(invalid='ignore'):
+                dP[sel] = np.sqrt(np.diagonal(pc, axis1=1, axis2=2))
+            chi[sel] = ch
+            status[sel] = st
+        return popt, dP, chi, status
+    return run
+
+
+def fit_batch_arrays(t, y, nParams, runner, active=None):
+    """conduct_curve_fitting(bReInitialise=True) for a batch.  Returns a dict of arrays over ALL n residues
+    (rows of inactive residues are undefined): ok, chiSq, quality (n,3), popt, dP, p0."""
+    n = y.shape[0]
+    K, free = split_nparams(nParams)
+    idx = np.arange(n) if active is None else np.flatnonzero(active)
+    res = dict(nParams=nParams, ok=np.zeros(n, dtype=bool), chiSq=np.full(n, np.inf), quality=np.zeros((n, 3), dtype=bool),
+               popt=np.full((n, nParams), np.nan), dP=np.full((n, nParams), np.nan), p0=np.full((n, nParams), np.nan))
+    if idx.size == 0:
+        return res
+    p0, C0, S2_0 = initial_guess_batch(t[idx], y[idx], nParams)
+    popt, dP, chi, status = runner(nParams, p0, idx)
+    ok = status > 0
+    # quality flags, fitting_Ct_functions.py:320-338 (sum>1 test on the initial guess: reference quirk)
+    with np.errstate(invalid='ignore'):
+        q1 = ~np.any(dP > popt, axis=1)
+    S2chk = S2_0 if free else 1.0 - np.sum(C0, axis=1)
+    q2 = ~(S2chk + np.sum(C0, axis=1) > 1.0)
+    res['p0'][idx] = p0
+    res['ok'][idx] = ok
+    res['chiSq'][idx] = np.where(ok, chi, np.inf)
+    res['quality'][idx] = np.stack([ok, np.where(ok, q1, True), np.where(ok, q2, True)], axis=1)
+    res['popt'][idx] = popt
+    res['dP'][idx] = dP
+    return res
+
+
+def _fit_dict(res, i):
+    """Per-residue view of a batch result with components sorted by tau (sort_components, :203-209)."""
+    nP = res['nParams']
+    K, free = split_nparams(nP)
+    f = dict(nParams=nP, ok=bool(res['ok'][i]), chiSq=float(res['chiSq'][i]), quality=list(res['quality'][i]), p0=res['p0'][i])
+    if not f['ok']:
+        return f
+    popt, dP = res['popt'][i], res['dP'][i]
+    C, tau = popt[:K], popt[K:2 * K]
+    order = np.argsort(tau)
+    f.update(popt=popt, dP=dP, C=C[order], tau=tau[order], dC=dP[:K][order], dtau=dP[K:2 * K][order],
+             S2=(popt[-1] if free else 1.0 - np.sum(C)), dS2=(dP[-1] if free else 0.0))
+    return f
+
+
+def fit_batch(t, y, dy, nParams, active=None, ctx=None):
+    """List-of-dicts form of fit_batch_arrays over host arrays (None for inactive residues)."""
+    res = fit_batch_arrays(t, y, nParams, host_runner(t, y, dy, ctx), active)
+    idx = np.arange(y.shape[0]) if active is None else np.flatnonzero(active)
+    out = [None] * y.shape[0]
+    for i in idx:
+        out[i] = _fit_dict(res, i)
+    return out
+
+
+def order_search_batch(t, y, runner, listDoG=(2, 3, 5, 7, 9), chiSqThreshold=0.5):
+    """optimised_curve_fitting (fitting_Ct_functions.py:278-304) for all residues in lock-step, vectorised:
+    each model order is one batched solve over the residues still searching.  Returns
+    (best_order_index (n,) with -1 = never satisfied, list of per-order batch results)."""
+    n = y.shape[0]
+    first = np.ones(n, dtype=bool)
+    done = np.zeros(n, dtype=bool)
+    best = np.full(n, -1, dtype=int)
+    best_chi = np.full(n, np.inf)
+    per_order = []
+    for j, nP in enumerate(listDoG):
+        active = ~done
+        if not active.any():
+            break
+        res = fit_batch_arrays(t, y, nP, runner, active)
+        per_order.append(res)
+        allq = res['quality'].all(axis=1)
+        chi = res['chiSq']
+        was_first = first.copy()
+        take_first = active & was_first & allq
+        best[take_first] = j
+        best_chi[take_first] = chi[take_first]
+        first[take_first] = False
+        later = active & ~was_first
+        stop = later & (~allq | (chi >= best_chi * chiSqThreshold))
+        done |= stop
+        acc = later & ~stop
+        best[acc] = j
+        best_chi[acc] = chi[acc]
+    return best, per_order
+
+
+def optimised_curve_fitting_batch(names, t, y, dy, listDoG=(2, 3, 5, 7, 9), chiSqThreshold=0.5, fp=sys.stdout, ctx=None,
+                                  return_trials=False, runner=None):
+    """Convenience wrapper: list of selected fit dicts (None where no order was ever satisfactory)."""
+    run = runner if runner is not None else host_runner(t, y, dy, ctx)
+    best, per_order = order_search_batch(t, y, run, listDoG, chiSqThreshold)
+    results = []
+    for i in range(y.shape[0]):
+        if fp is not None:
+            for res in per_order:
+                if np.isfinite(res['p0'][i, 0]):
+                    print("    ...fit of %s with %i params yield chiSq of %g" % (names[i], res['nParams'], res['chiSq'][i]), file=fp)
+        if best[i] < 0:
+            if fp is not None:
+                print("    ...ERROR: fit of %s has never generated a satisfactory outcome!" % names[i], file=fp)
+            results.append(None)
+        else:
+            results.append(_fit_dict(per_order[best[i]], i))
+    if return_trials:
+        trials = [[_fit_dict(res, i) for res in per_order if np.isfinite(res['p0'][i, 0])] for i in range(y.shape[0])]
+        return results, trials
+    return results
+
+
+# ---------------------------------------------------------------------------------------------------
+# _fittedCt.dat reader
+# ---------------------------------------------------------------------------------------------------
+def read_fittedCt_parameters(fileName):
+    """fitting_Ct_functions.py:432-481: header lines '# Residue: n', '# Param <name>: <v> +- <e>'; a
+    section ends at the first non-comment line."""
+    obj = autoCorrelations()
+    index = None
+    S2_slow = None
+    S2_fast = None
+    tmpC = OrderedDict()
+    tmpTau = OrderedDict()
+    inside = False
+    with open(fileName) as fp:
+        for line in fp.readlines():
+            if line.startswith("#"):
+                l = line.split()
+                if l[1].startswith("Residue"):
+                    if inside:
+                        print("= = = ERROR in read_fittedCt_parameters: New parameter section detected when old parameter section is still being read! %s " % fileName, file=sys.stderr)
+                        sys.exit(1)
+                    inside = True
+                    index = str(l[-1])
+                elif l[1].startswith("Param"):
+                    parName = l[2]
+                    value = float(l[-3])
+                    if parName.startswith("S2_0"):
+                        S2_slow = value
+                    elif parName.startswith("S2_fast"):
+                        S2_fast = value
+                    elif parName.startswith("C_"):
+                        tmpC[str(index) + "-" + parName[2]] = value
+                    elif parName.startswith("tau_"):
+                        tmpTau[str(index) + "-" + parName[4]] = value
+            elif inside:
+                obj.add_model(index, S2=S2_slow, listC=[tmpC[k] for k in tmpC.keys()], listTau=[tmpTau[k] for k in tmpC.keys()],
+                              bS2Fast=S2_fast is not None)
+                inside = False
+                tmpC = OrderedDict()
+                tmpTau = OrderedDict()
+                S2_fast = None
+                S2_slow = None
+                index = None
+    return obj

@@ -1,0 +1,252 @@
+"""
+numpy-facing wrapper around the C ABI (spinrelax_amd/_lib.py -> libspinrelax_hip.so).
+
+`Context` owns one sr_ctx (one GPU).  Methods without the `_dev` suffix take and return numpy arrays
+(host buffers, blocking); `_dev` methods take raw device addresses (ints, e.g. torch
+``tensor.data_ptr()``) and only enqueue work on the context's stream.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import SpinRelaxHipError, check
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        self.h = self.lib.sr_create(int(device))
+        if not self.h:
+            raise SpinRelaxHipError('sr_create(%d) failed: %s' % (device, _lib.last_error()))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.sr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- plumbing ----
+    def set_stream(self, stream_handle):
+        check(self.lib.sr_set_stream(self.h, ctypes.c_void_p(stream_handle or 0)), 'sr_set_stream')
+
+    def sync(self):
+        check(self.lib.sr_sync(self.h), 'sr_sync')
+
+    def device_info(self):
+        ncu = ctypes.c_int()
+        hbm = ctypes.c_int64()
+        lds = ctypes.c_int()
+        name = ctypes.create_string_buffer(256)
+        check(self.lib.sr_device_info(self.h, ctypes.byref(ncu), ctypes.byref(hbm), ctypes.byref(lds), name, 256),
+              'sr_device_info')
+        return dict(n_cu=ncu.value, hbm_bytes=hbm.value, lds_per_cu=lds.value, name=name.value.decode())
+
+    def timer_start(self):
+        check(self.lib.sr_timer_start(self.h), 'sr_timer_start')
+
+    def timer_stop_ms(self):
+        ms = ctypes.c_float()
+        check(self.lib.sr_timer_stop_ms(self.h, ctypes.byref(ms)), 'sr_timer_stop_ms')
+        return ms.value
+
+    def max_frames_per_chunk(self):
+        return int(self.lib.sr_ct_max_frames_per_chunk(self.h))
+
+    # ---- kernel 1 ----
+    def ct_palmer(self, vecs, R, F, v0=0, nV=None, chunk_start=None, mode=0):
+        """vecs (N, Vtot, 3) float32 -> Ct, dCt (F//2, nV) float64.  calculate-Ct-from-traj.py:200-238."""
+        vecs = _f32(vecs)
+        if vecs.ndim != 3 or vecs.shape[2] != 3:
+            raise ValueError('vecs must be (N, V, 3)')
+        N, Vtot, _ = vecs.shape
+        nV = Vtot - v0 if nV is None else nV
+        L = F // 2
+        Ct = np.empty((L, nV))
+        dCt = np.empty((L, nV))
+        cs = None if chunk_start is None else np.ascontiguousarray(chunk_start, dtype=np.int64)
+        if cs is not None and cs.shape != (R,):
+            raise ValueError('chunk_start must have R entries')
+        check(self.lib.sr_ct_palmer_f32(self.h, _ptr(vecs), N, Vtot, v0, nV, R, F, _ptr(cs), int(mode), _ptr(Ct), _ptr(dCt)),
+              'sr_ct_palmer_f32')
+        return Ct, dCt
+
+    def pack_soa_dev(self, vecs_ptr, N, Vtot, v0, nV, soa_ptr, Npad):
+        check(self.lib.sr_pack_soa_f32_dev(self.h, vecs_ptr, N, Vtot, v0, nV, soa_ptr, Npad), 'sr_pack_soa_f32_dev')
+
+    def ct_palmer_dev(self, soa_ptr, Npad, R, F, nV, Ct_ptr, dCt_ptr, chunk_start=None, mode=0, psum_ptr=None):
+        cs = None if chunk_start is None else np.ascontiguousarray(chunk_start, dtype=np.int64)
+        check(self.lib.sr_ct_palmer_f32_dev(self.h, soa_ptr, Npad, R, F, nV, _ptr(cs), int(mode), psum_ptr, Ct_ptr, dCt_ptr),
+              'sr_ct_palmer_f32_dev')
+
+    def psum_stride(self, F):
+        return int(self.lib.sr_ct_psum_stride(F))
+
+    # ---- kernel 2 ----
+    def rotate_hist(self, vecs, q, edges_phi, edges_cos, v0=0, nV=None, block_len=0, want_outer=True):
+        """vecs (N, Vtot, 3) float32 -> hist (nV, nphi, ncos), vecsum (nV,3), outer (nB, nV, 6)."""
+        vecs = _f32(vecs)
+        N, Vtot, _ = vecs.shape
+        nV = Vtot - v0 if nV is None else nV
+        ep = _f64(edges_phi)
+        ec = _f64(edges_cos)
+        nphi, ncos = ep.size - 1, ec.size - 1
+        qq = None if q is None else _f64(q)
+        hist = np.empty((nV, nphi, ncos))
+        vecsum = np.empty((nV, 3))
+        Fb = block_len if (block_len and 0 < block_len <= N) else N
+        nB = N // Fb
+        outer = np.empty((nB, nV, 6)) if want_outer else None
+        check(self.lib.sr_rotate_hist_f32(self.h, _ptr(vecs), N, Vtot, v0, nV, _ptr(qq), _ptr(ep), nphi, _ptr(ec), ncos,
+                                          _ptr(hist), _ptr(vecsum), _ptr(outer), int(block_len or 0)), 'sr_rotate_hist_f32')
+        return hist, vecsum, outer
+
+    def rotate_hist_dev(self, soa_ptr, Npad, N, nV, q, edges_phi, edges_cos, hist_ptr, vecsum_ptr, outer_ptr, block_len):
+        ep = _f64(edges_phi)
+        ec = _f64(edges_cos)
+        qq = None if q is None else _f64(q)
+        check(self.lib.sr_rotate_hist_f32_dev(self.h, soa_ptr, Npad, N, nV, _ptr(qq), _ptr(ep), ep.size - 1, _ptr(ec),
+                                              ec.size - 1, hist_ptr, vecsum_ptr, outer_ptr, int(block_len or 0)),
+              'sr_rotate_hist_f32_dev')
+
+    def rotate_vectors(self, vecs, q, v0=0, nV=None):
+        vecs = _f32(vecs)
+        N, Vtot, _ = vecs.shape
+        nV = Vtot - v0 if nV is None else nV
+        out = np.empty((N, nV, 3))
+        qq = None if q is None else _f64(q)
+        check(self.lib.sr_rotate_vectors_f32(self.h, _ptr(vecs), N, Vtot, v0, nV, _ptr(qq), _ptr(out)), 'sr_rotate_vectors_f32')
+        return out
+
+    # ---- kernel 3b ----
+    def expfit_resjac(self, t, y, sigma, params, want_jac=True):
+        t = _f64(np.atleast_2d(t))
+        y = _f64(np.atleast_2d(y))
+        nRes, L = y.shape
+        if t.shape[0] == 1 and nRes > 1:
+            t = _f64(np.broadcast_to(t, (nRes, L)))
+        s = None if sigma is None else _f64(np.atleast_2d(sigma))
+        p = _f64(np.atleast_2d(params))
+        P = p.shape[1]
+        resid = np.empty((nRes, L))
+        jac = np.empty((nRes, L, P)) if want_jac else None
+        check(self.lib.sr_expfit_resjac_f64(self.h, _ptr(t), _ptr(y), _ptr(s), _ptr(p), nRes, L, P, _ptr(resid), _ptr(jac)),
+              'sr_expfit_resjac_f64')
+        return resid, jac
+
+    def expfit(self, t, y, sigma, p0, tau_max, max_nfev=0, analytic_jac=False):
+        """Batched bounded fit (scipy curve_fit/TRF semantics).  Returns popt, pcov, chisq, status, nfev."""
+        y = _f64(np.atleast_2d(y))
+        nRes, L = y.shape
+        t = _f64(np.broadcast_to(np.atleast_2d(t), (nRes, L)))
+        s = None if sigma is None else _f64(np.broadcast_to(np.atleast_2d(sigma), (nRes, L)))
+        p0 = _f64(np.atleast_2d(p0))
+        P = p0.shape[1]
+        popt = np.empty((nRes, P))
+        pcov = np.empty((nRes, P, P))
+        chisq = np.empty(nRes)
+        status = np.empty(nRes, dtype=np.int32)
+        nfev = np.empty(nRes, dtype=np.int32)
+        mi = int(max_nfev) if max_nfev else 100 * P
+        if analytic_jac:
+            mi = -mi
+        check(self.lib.sr_expfit_lm_f64(self.h, _ptr(t), _ptr(y), _ptr(s), nRes, L, P, _ptr(p0), float(tau_max), mi,
+                                        _ptr(popt), _ptr(pcov), _ptr(chisq), _ptr(status), _ptr(nfev)), 'sr_expfit_lm_f64')
+        return popt, pcov, chisq, status, nfev
+
+    def expfit_dev(self, t_ptr, y_ptr, sigma_ptr, nRes, L, P, p0_ptr, tau_max, max_nfev, popt_ptr, pcov_ptr, chisq_ptr,
+                   status_ptr, nfev_ptr, skip_ptr=None):
+        check(self.lib.sr_expfit_lm_f64_dev(self.h, t_ptr, y_ptr, sigma_ptr, nRes, L, P, p0_ptr, float(tau_max),
+                                            int(max_nfev), skip_ptr, popt_ptr, pcov_ptr, chisq_ptr, status_ptr, nfev_ptr),
+              'sr_expfit_lm_f64_dev')
+
+    def transpose_dev(self, in_ptr, rows, cols, out_ptr):
+        check(self.lib.sr_transpose_f64_dev(self.h, in_ptr, rows, cols, out_ptr), 'sr_transpose_f64_dev')
+
+    # ---- kernel 3a ----
+    def jomega(self, x, y):
+        x, y = np.broadcast_arrays(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64))
+        xs = _f64(x)
+        ys = _f64(y)
+        out = np.empty(xs.shape)
+        check(self.lib.sr_jomega_f64(self.h, _ptr(xs), _ptr(ys), _ptr(out), xs.size), 'sr_jomega_f64')
+        return out
+
+    def relax(self, model, D, omega, f_DD, f_CSA, time_fact, gamma_ratio, S2, C, tau, nComps,
+              binvecs=None, weights=None, resvecs=None, noe_mode=0, want_J=False, weights_dev_ptr=None):
+        """model 0 direct / 1 sphere (D=[Diso]) / 2 symmetric top (D=[Dpar, Dperp]).
+        Symmetric top: either `binvecs` (B,3) shared by all residues with optional `weights` (nRes,B), or
+        `resvecs` (nRes,3), one vector per residue.  Returns out (E, nRes, 4, 2) = [R1,R2,NOE,rho] x
+        [mean, sigma] and J (E, nRes, 5, 2) or None."""
+        omega = _f64(np.atleast_2d(omega))
+        E = omega.shape[0]
+        S2 = _f64(S2)
+        nRes = S2.size
+        C = _f64(np.atleast_2d(C))
+        tau = _f64(np.atleast_2d(tau))
+        Kmax = C.shape[1]
+        f_DD = _f64(np.broadcast_to(f_DD, (E,)))
+        f_CSA = _f64(np.broadcast_to(f_CSA, (E, nRes)))
+        time_fact = _f64(np.broadcast_to(time_fact, (E,)))
+        gamma_ratio = _f64(np.broadcast_to(gamma_ratio, (E,)))
+        nc = np.ascontiguousarray(nComps, dtype=np.int32)
+        Dd = None if D is None else _f64(np.atleast_1d(D))
+        B = 0
+        bv = None
+        w = None
+        if model == 2:
+            if binvecs is not None:
+                bv = _f64(binvecs)
+                B = bv.shape[0]
+                if weights is not None:
+                    w = _f64(weights)
+                    if w.shape != (nRes, B):
+                        raise ValueError('weights must be (nRes, B)')
+            elif resvecs is not None:
+                bv = _f64(resvecs)
+                if bv.shape != (nRes, 3):
+                    raise ValueError('resvecs must be (nRes, 3)')
+            else:
+                raise ValueError('symmetric-top model needs binvecs or resvecs')
+        out = np.empty((E, nRes, 4, 2))
+        J = np.empty((E, nRes, 5, 2)) if want_J else None
+        check(self.lib.sr_jomega_relax_f64(self.h, int(model), _ptr(Dd), E, _ptr(omega), _ptr(f_DD), _ptr(f_CSA),
+                                           _ptr(time_fact), _ptr(gamma_ratio), nRes, Kmax, _ptr(S2), _ptr(C), _ptr(tau),
+                                           _ptr(nc), B, _ptr(bv), weights_dev_ptr if weights_dev_ptr else _ptr(w),
+                                           1 if weights_dev_ptr else 0, int(noe_mode), _ptr(out), _ptr(J)),
+              'sr_jomega_relax_f64')
+        return out, J
+
+
+_default = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (created on first use)."""
+    if device not in _default or _default[device].h is None:
+        _default[device] = Context(device)
+    return _default[device]

@@ -1,0 +1,408 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X).  Every test calls the HIP path through the C ABI
+(spinrelax_amd.hip.Context -> libspinrelax_hip.so) and checks it against
+  * the committed golden vectors produced by the real reference (tests/golden/), and
+  * the CPU oracle (oracle/) on the same seeded inputs.
+Tolerances: integer work (histogram counts) bit-exact; floating point 1e-6 relative as BASELINE.json's
+north_star states, written next to each assertion.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, relerr
+import sr_oracle as o
+from spinrelax_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6            # north_star: C(t), J(w), R1/R2/NOE within 1e-6 relative
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from spinrelax_amd.hip import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope='module')
+def liboracle():
+    so = os.path.join(ROOT, 'oracle', 'libsr_oracle.so')
+    if not os.path.isfile(so):
+        subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'libsr_oracle.so'])
+    lib = ctypes.CDLL(so)
+    lib.sr_oracle_ct_palmer_f64.restype = ctypes.c_int
+    return lib
+
+
+def c_oracle_ct(lib, v4):
+    v4 = np.ascontiguousarray(v4, dtype=np.float32)
+    R, F, V, _ = v4.shape
+    L = F // 2
+    Ct = np.empty((L, V))
+    dCt = np.empty((L, V))
+    rc = lib.sr_oracle_ct_palmer_f64(v4.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(R), ctypes.c_int64(F),
+                                     ctypes.c_int64(V), Ct.ctypes.data_as(ctypes.c_void_p),
+                                     dCt.ctypes.data_as(ctypes.c_void_p), None)
+    assert rc == 0
+    return Ct, dCt
+
+
+def dct_close(dCt, ref, R, F):
+    """dC(t) = std over the R replicate means p_r / (sqrt(R) - 1).  The bar is set on the quantity the
+    kernel computes, p_r: 1e-6 / sqrt(F/2) absolute (float32 rounding of the dot products, 1e-7 per term,
+    averaged over F/2..F terms) -- i.e. well inside 1e-6 relative of C(t) -- and propagated through the
+    std: |d dCt| <= that / (sqrt(R) - 1).  For scale: the reference's own float32 dC(t) is off by
+    1e-4 .. 31 % relative and its _Ctint.dat keeps 8 decimals."""
+    err = np.abs(dCt - ref)
+    atol = 1e-6 / np.sqrt(F / 2.0) / (np.sqrt(R) - 1.0)
+    return np.all(err <= np.maximum(RTOL * np.abs(ref), atol))
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel 1: C(t)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag,cfg,nvec', [('cfg1', 1, None), ('cfg2', 2, None), ('cfg3s', 3, 8)])
+@pytest.mark.parametrize('mode', [0, 1])
+def test_ct_vs_golden(ctx, synth_cache, tag, cfg, nvec, mode):
+    g = golden('%s_ct.npz' % tag)
+    s = synth.config_shapes(cfg)
+    vecs = synth_cache(cfg, nvec)
+    Ct, dCt = ctx.ct_palmer(vecs, s['R'], s['F'], mode=mode)
+    assert Ct.shape == g['Ct64'].shape
+    tol = RTOL if mode == 0 else 1e-12
+    assert relerr(Ct, g['Ct64']) < tol
+    if mode == 1:
+        assert relerr(dCt, g['dCt64']) < 1e-9
+    else:
+        assert dct_close(dCt, g['dCt64'], s['R'], s['F'])
+        # in practice the fast path is far inside the bar: record it
+        assert relerr(Ct, g['Ct64']) < 1e-7
+
+
+def test_ct_sharded_vector_range(ctx, synth_cache):
+    """v0/nV select a shard of the vectors; results must equal the full run's columns."""
+    s = synth.config_shapes(1)
+    vecs = synth_cache(1)
+    full, dfull = ctx.ct_palmer(vecs, s['R'], s['F'])
+    part, dpart = ctx.ct_palmer(vecs, s['R'], s['F'], v0=5, nV=11)
+    np.testing.assert_array_equal(part, full[:, 5:16])
+    np.testing.assert_array_equal(dpart, dfull[:, 5:16])
+
+
+@pytest.mark.parametrize('F,R,V', [(2, 3, 2), (3, 2, 1), (7, 4, 3), (64, 3, 5), (254, 2, 3), (255, 2, 3), (256, 2, 3),
+                                   (257, 3, 2), (510, 2, 2), (1000, 2, 3), (1026, 2, 2), (100, 1, 2)])
+def test_ct_ragged_and_edge_sizes(ctx, liboracle, F, R, V):
+    """odd / tiny / just-around-a-lag-block chunk lengths, R = 1 (dCt = NaN like numpy), tail frames ignored"""
+    vecs = synth.synth_vectors(R * F + 3, V, seed=100 + F)      # 3 trailing frames must be ignored
+    v4 = vecs[:R * F].reshape(R, F, V, 3)
+    Cr, dCr = c_oracle_ct(liboracle, v4)
+    for mode in (0, 1):
+        Ct, dCt = ctx.ct_palmer(vecs, R, F, mode=mode)
+        assert Ct.shape == (F // 2, V)
+        assert relerr(Ct, Cr) < RTOL
+        if R == 1:
+            assert np.all(np.isnan(dCt)) and np.all(np.isnan(dCr))
+        else:
+            assert dct_close(dCt, dCr, R, F)
+
+
+def test_ct_multi_file_chunk_starts(ctx, liboracle):
+    """reformat_vecs_by_tau drops each file's tail separately (calculate-Ct-from-traj.py:259-272)."""
+    from spinrelax_amd import ct as hostct
+    a = synth.synth_vectors(700, 4, seed=11)
+    b = synth.synth_vectors(530, 4, seed=12)
+    F = 200
+    v4 = o.reformat_vecs_by_tau([a, b], 1.0, float(F))
+    cat, starts, R = hostct.concat_with_chunk_starts([a, b], F)
+    assert R == v4.shape[0] == 5
+    Ct, dCt = ctx.ct_palmer(cat, R, F, chunk_start=starts)
+    Cr, dCr = c_oracle_ct(liboracle, v4)
+    assert relerr(Ct, Cr) < RTOL and dct_close(dCt, dCr, R, F)
+
+
+def test_ct_size_independent_properties(ctx):
+    """Properties that hold at any size: rotation invariance, time reversal, constant vector -> C(t)=1."""
+    s = synth.config_shapes(2)
+    vecs = synth.synth_config(2, nvec=16)
+    Ct, dCt = ctx.ct_palmer(vecs, s['R'], s['F'])
+    # (1) a fixed rotation of every frame leaves P2(u.u') unchanged
+    q = np.array([0.5, -0.5, 0.5, 0.5])
+    rot = o.rotate_vector_simd(vecs, q).astype(np.float32)
+    Ct2, _ = ctx.ct_palmer(rot, s['R'], s['F'])
+    assert relerr(Ct2, Ct) < 5e-7          # inputs re-rounded to float32
+    # (2) reversing time inside every chunk leaves the autocorrelation unchanged
+    N = s['R'] * s['F']
+    rev = vecs[:N].reshape(s['R'], s['F'], -1, 3)[:, ::-1].reshape(N, -1, 3)
+    Ct3, _ = ctx.ct_palmer(np.ascontiguousarray(rev), s['R'], s['F'])
+    assert relerr(Ct3, Ct) < 1e-7
+    # (3) constant unit vectors: C(t) == 1 exactly representable sums, dCt == 0
+    const = np.zeros((N, 3, 3), dtype=np.float32)
+    const[:, 0, 0] = 1.0
+    const[:, 1, 1] = 1.0
+    const[:, 2, 2] = -1.0
+    Ct4, dCt4 = ctx.ct_palmer(const, s['R'], s['F'])
+    np.testing.assert_array_equal(Ct4, 1.0)
+    np.testing.assert_array_equal(dCt4, 0.0)
+    # (4) C(t) of a unit vector is bounded: -0.5 <= C <= 1
+    assert Ct.max() <= 1.0 + 1e-12 and Ct.min() >= -0.5
+
+
+def test_ct_rejects_bad_arguments(ctx):
+    from spinrelax_amd.hip import SpinRelaxHipError
+    vecs = synth.synth_vectors(100, 2, seed=1)
+    with pytest.raises(SpinRelaxHipError):
+        ctx.ct_palmer(vecs, 2, 100)                      # R*F exceeds the frames given
+    with pytest.raises(SpinRelaxHipError):
+        ctx.ct_palmer(vecs, 1, 1)                        # F < 2
+    big = ctx.max_frames_per_chunk() + 64
+    with pytest.raises(SpinRelaxHipError):
+        ctx.ct_palmer(np.zeros((big, 1, 3), np.float32), 1, big)   # does not fit LDS: loud error, no fallback
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel 2: rotate + histogram + mean vector + S2
+# ------------------------------------------------------------------------------------------------
+def s2_from_outer(outer, Fb):
+    """calculate_S2_by_outerProduct (calculate-Ct-from-traj.py:133-142) from the per-block sums."""
+    m = outer / Fb                                         # (nB, V, 6): xx yy zz xy xz yz
+    s = 1.5 * (m[..., 0] ** 2 + m[..., 1] ** 2 + m[..., 2] ** 2 + 2 * (m[..., 3] ** 2 + m[..., 4] ** 2 + m[..., 5] ** 2)) - 0.5
+    nB = s.shape[0]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return np.stack((s.mean(axis=0), s.std(axis=0) / (np.sqrt(nB) - 1.0)), axis=-1)
+
+
+@pytest.mark.parametrize('tag,cfg', [('cfg1', 1), ('cfg2', 2)])
+def test_vechist_vs_golden(ctx, synth_cache, tag, cfg):
+    g = golden('%s_vec.npz' % tag)
+    s = synth.config_shapes(cfg)
+    vecs = synth_cache(cfg)[: s['N']]
+    hist, vecsum, outer = ctx.rotate_hist(vecs, g['q'], g['edges_phi'], g['edges_cos'], block_len=s['F'])
+    # integer work: bit-exact
+    np.testing.assert_array_equal(hist.astype(np.uint32), g['hist'])
+    assert hist.sum() == g['hist_sum'] == s['N'] * s['V']
+    avg = vecsum / s['N']
+    avg = avg / np.sqrt((avg ** 2).sum(-1))[:, None]
+    assert relerr(avg, g['avgvec']) < 1e-12
+    assert relerr(s2_from_outer(outer, s['F']), g['S2_tau']) < 1e-9
+    _, _, outer_all = ctx.rotate_hist(vecs, g['q'], g['edges_phi'], g['edges_cos'], block_len=0)
+    m = outer_all[0] / s['N']
+    S2all = 1.5 * (m[:, 0] ** 2 + m[:, 1] ** 2 + m[:, 2] ** 2 + 2 * (m[:, 3] ** 2 + m[:, 4] ** 2 + m[:, 5] ** 2)) - 0.5
+    assert relerr(S2all, g['S2_all']) < 1e-12
+    rot = ctx.rotate_vectors(vecs, g['q'])
+    np.testing.assert_array_equal(rot[g['rot_idx_n'], g['rot_idx_v']], g['rot_sample'])
+
+
+def test_vechist_edge_cases(ctx):
+    """poles, the phi = +-pi seam, exact bin edges, zero vectors (NaN -> dropped like numpy), no rotation"""
+    e = o.lambert_edges()
+    v = np.array([[0, 0, 1], [0, 0, -1], [-1, 0, 0], [-1, -0.0, 0], [1, 0, 0], [0, 1, 0], [0, -1, 0],
+                  [0, 0, 0], [0.6, 0.8, 0], [1e-30, 0, 1], [np.cos(np.pi / 36), np.sin(np.pi / 36), 0.5]], dtype=np.float32)
+    vecs = np.ascontiguousarray(v[:, None, :])                  # (11 frames, 1 vector)
+    hist, vecsum, outer = ctx.rotate_hist(vecs, None, e[0], e[1])
+    ref, _ = o.lambert_histogram(vecs.astype(np.float64))
+    np.testing.assert_array_equal(hist, ref)
+    assert hist.sum() == 10                                     # the zero vector is dropped
+    # identity quaternion given explicitly behaves the same
+    hist2, _, _ = ctx.rotate_hist(vecs, [2.0, 0, 0, 0], e[0], e[1])
+    np.testing.assert_array_equal(hist2, ref)
+    # other resolutions (--histBin)
+    for nphi in (8, 36, 90):
+        ee = o.lambert_edges(nphi)
+        vv = synth.synth_vectors(500, 3, seed=5)
+        h, _, _ = ctx.rotate_hist(vv, synth.Q_EXT, ee[0], ee[1])
+        r, _ = o.lambert_histogram(o.rotate_vector_simd(vv, np.array(synth.Q_EXT)), nphi)
+        np.testing.assert_array_equal(h, r)
+
+
+def test_vechist_full_size_properties(ctx):
+    """cfg3-shaped slice: every frame lands in exactly one bin; rotating by q then by q^-1 restores the
+    unrotated histogram."""
+    s = synth.config_shapes(3)
+    vecs = synth.synth_config(3, nvec=8)[: s['N']]
+    e = o.lambert_edges()
+    h0, vs0, _ = ctx.rotate_hist(vecs, None, e[0], e[1], block_len=s['F'])
+    assert np.all(h0.sum(axis=(1, 2)) == s['N'])
+    q = np.array(synth.Q_EXT)
+    rot = ctx.rotate_vectors(vecs, q)
+    qinv = q * np.array([1, -1, -1, -1])
+    back = ctx.rotate_vectors(rot.astype(np.float32), qinv)
+    assert np.max(np.abs(back - vecs)) < 5e-7
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel 3a: J(omega), R1/R2/NOE/rho
+# ------------------------------------------------------------------------------------------------
+def relax_inputs(g):
+    n = len(g['names'])
+    zeta = float(g['zeta'])
+    return n, zeta * g['S2'], zeta * g['C'], g['tau'], g['nComps'].astype(np.int32)
+
+
+def old_api_consts(MHz, csa, n):
+    B0 = o.B0_from_Hz(MHz * 1e6)
+    om = o.omega_set(B0, 'ps')
+    fcsa = o.factor_CSA(np.broadcast_to(np.asarray(csa, dtype=float), (n,)), B0)
+    return om, o.factor_DD(), fcsa, 1e-12, o.GAMMA['1H'] / o.GAMMA['15N']
+
+
+def test_jomega_ufunc_twin(ctx):
+    import json
+    k = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'known_answers.json')))['Jomega_outer']
+    x = np.array(k['x'])[:, None]
+    y = np.array(k['y'])[None, :]
+    out = ctx.jomega(x, y)
+    assert relerr(out, np.array(k['out'])) < 1e-15
+    z = ctx.jomega(np.array([0.0, 1.0]), np.array([0.0, 0.0]))
+    assert np.isnan(z[0]) and z[1] == 1.0                      # 0/0 like the C loop
+
+
+def test_relax_old_api_vs_golden(ctx):
+    g = golden('cfg1_relax.npz')
+    n, S2, C, tau, K = relax_inputs(g)
+    Dpar, Dperp = o.symmtop_from_iso(float(g['Diso']), float(g['Dani']))
+    for fi, MHz in enumerate(g['fields']):
+        om, fdd, fcsa, tf, gr = old_api_consts(MHz, -170e-6, n)
+        out, J = ctx.relax(1, [float(g['Diso'])], om, fdd, fcsa, tf, gr, S2, C, tau, K, want_J=True)
+        assert relerr(out[0, :, :, 0].T, g['iso_f64_%d' % fi]) < 1e-12     # float64 values of the reference
+        assert relerr(J[0, :, :, 0], g['iso_J_%d' % fi]) < 1e-12
+        # and what the reference finally writes: its float32 datablock
+        np.testing.assert_allclose(out[0, :, :, 0].T.astype(np.float32), g['iso_f32_%d' % fi], rtol=2e-7)
+        for nm, csa in (('sym', -170e-6), ('symcsa', g['csa_alt'])):
+            om, fdd, fcsa, tf, gr = old_api_consts(MHz, csa, n)
+            out, J = ctx.relax(2, [Dpar, Dperp], om, fdd, fcsa, tf, gr, S2, C, tau, K,
+                               binvecs=g['binvecs'], weights=g['weights'], noe_mode=0, want_J=True)
+            ref = g['%s_f64_%d' % (nm, fi)]                                  # (4, n, 2)
+            got = np.transpose(out[0], (1, 0, 2))
+            assert relerr(got[..., 0], ref[..., 0]) < 1e-11                  # weighted means
+            assert relerr(got[..., 1], ref[..., 1]) < 1e-8                   # weighted sigmas
+            np.testing.assert_allclose(got.astype(np.float32), g['%s_f32_%d' % (nm, fi)], rtol=3e-7)
+        # one vector per residue (calculate-relaxations-from-Ct.py:177-187)
+        om, fdd, fcsa, tf, gr = old_api_consts(MHz, -170e-6, n)
+        out, _ = ctx.relax(2, [Dpar, Dperp], om, fdd, fcsa, tf, gr, S2, C, tau, K, resvecs=g['sym1_vecs'])
+        np.testing.assert_allclose(out[0, :, :, 0].T.astype(np.float32), g['sym1_f32_%d' % fi], rtol=3e-7)
+        assert np.all(out[..., 1] == 0)
+
+
+def test_relax_new_api_vs_golden(ctx):
+    """class API: NOE from the vector-averaged R1 (spectral_densities.py:881-892); all 9 experiments at once"""
+    g = golden('cfg1_relax.npz')
+    n = len(g['names'])
+    zeta = float(g['zeta'])
+    S2, C, tau, K = zeta * g['S2'], zeta * g['C'], g['tau'], g['nComps'].astype(np.int32)
+    Dpar, Dperp = o.symmtop_from_iso(float(g['Diso']), float(g['Dani']))
+    oms, fcs = [], []
+    for MHz in g['fields']:
+        om, B0 = o.omega_set_new(MHz)
+        oms.append(om)
+        fcs.append(np.repeat(2.0 / 15.0 * (-170e-6) ** 2.0 * (o.GAMMA['15N'] * B0) ** 2, n))
+    out, _ = ctx.relax(2, [Dpar, Dperp], np.array(oms), o.factor_DD_new(), np.array(fcs), 1e-12,
+                       o.GAMMA['1H'] / o.GAMMA['15N'], S2, C, tau, K, binvecs=g['binvecs'], weights=g['weights'], noe_mode=1)
+    for fi in range(3):
+        for qi, kind in enumerate(('R1', 'R2', 'NOE')):
+            assert relerr(out[fi, :, qi, 0], g['new_%s_val_%d' % (kind, fi)]) < 1e-11
+            assert relerr(out[fi, :, qi, 1], g['new_%s_err_%d' % (kind, fi)]) < 1e-8
+    # old and new NOE differ by design: make sure both modes are really different code
+    out0, _ = ctx.relax(2, [Dpar, Dperp], np.array(oms), o.factor_DD_new(), np.array(fcs), 1e-12,
+                        o.GAMMA['1H'] / o.GAMMA['15N'], S2, C, tau, K, binvecs=g['binvecs'], weights=g['weights'], noe_mode=0)
+    assert 1e-6 < relerr(out0[:, :, 2, 0], out[:, :, 2, 0]) < 1e-2
+    np.testing.assert_array_equal(out0[:, :, :2], out[:, :, :2])
+
+
+def test_relax_known_answer_rigid_sphere(ctx):
+    """--theoretical known answer: rigid sphere, S2 = zeta, no internal motion."""
+    om, fdd, fcsa, tf, gr = old_api_consts(600.133, -170e-6, 1)
+    out, _ = ctx.relax(1, [3.7383e-5], om, fdd, fcsa, tf, gr, [0.890023], [[0.0]], [[99999.0]], [1])
+    assert abs(out[0, 0, 0, 0] / 2.216697349136826 - 1) < 1e-13
+    assert abs(out[0, 0, 1, 0] / 6.743109911585374 - 1) < 1e-13
+    assert abs(out[0, 0, 2, 0] / 0.7864966280916813 - 1) < 1e-13
+    # direct transform model (no global tumbling)
+    out, J = ctx.relax(0, None, om, fdd, fcsa, tf, gr, [0.8], [[0.1, 0.1]], [[50.0, 900.0]], [2], want_J=True)
+    assert relerr(J[0, 0, :, 0], o.J_direct_transform(om, [0.1, 0.1], [50.0, 900.0])) < 1e-14
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel 3b: multi-exponential model, device TRF fit
+# ------------------------------------------------------------------------------------------------
+def test_resjac_vs_oracle_and_reference_chi(ctx):
+    g = golden('cfg2_fit.npz')
+    t, y, dy = g['t'], g['y'], g['dy']
+    for j, nP in enumerate(g['listDoG']):
+        ok = g['trial_quality'][:, j, 0]
+        p = g['trial_popt'][ok, j, :nP]
+        resid, jac = ctx.expfit_resjac(t[ok], y[ok], dy[ok], p)
+        for i in range(p.shape[0]):
+            model = o.curvefit_exponential(t[ok][i], *p[i])
+            assert relerr(resid[i] * dy[ok][i] + y[ok][i], model) < 1e-13
+            # chi^2 of the reference at the reference's optimum (tier (i) of the fit parity contract)
+            chi = np.mean((resid[i] * dy[ok][i]) ** 2 / dy[ok][i])
+            assert abs(chi / g['trial_chi'][ok][i, j] - 1) < 1e-9
+        # analytic Jacobian vs central differences of the oracle model
+        i = 0
+        for k in range(nP):
+            h = 1e-6 * max(1.0, abs(p[i, k]))
+            pp, pm = p[i].copy(), p[i].copy()
+            pp[k] += h
+            pm[k] -= h
+            fd = (o.curvefit_exponential(t[ok][i], *pp) - o.curvefit_exponential(t[ok][i], *pm)) / (2 * h) / dy[ok][i]
+            assert np.max(np.abs(jac[i, :, k] - fd)) <= 1e-6 * max(1.0, np.max(np.abs(fd)))
+
+
+@pytest.mark.parametrize('tag', ['cfg1', 'cfg2', 'cfg3s'])
+def test_device_fit_vs_reference_trials(ctx, tag):
+    """Every (residue, model order) trial of the fixtures, started from the reference's own p0.
+
+    The device solver restates scipy's TRF step for step (sr_fit.hip) and normally needs exactly the
+    same number of function evaluations.  What limits agreement is the reference itself: scipy's result
+    moves by 1e-7 .. 3e-5 in chi^2 (and sometimes in nfev) when exp() changes by one ulp
+    (DESIGN.md "fit parity", measured with the real scipy), because ftol = xtol = 1e-8 stop a run
+    ~1e-4 from the stationary point along flat directions.  Hence the tiers:
+      (i)  chi^2 at the reference's optimum: 1e-9 (test_resjac_vs_oracle_and_reference_chi);
+      (ii) fitted chi^2 within 1e-4 for the well-conditioned orders (<= 5 parameters), failures of the
+           reference reproduced exactly (same residues fail for the same reason);
+      (iii) over-parameterised orders (7, 9 parameters; the reference flags most of them as
+           over-fitted) are only required to reach a comparable minimum."""
+    g = golden('%s_fit.npz' % tag)
+    t, y, dy = g['t'], g['y'], g['dy']
+    nres = y.shape[0]
+    tau_max = t[0, -1] * 10
+    lo_tot = lo_ok = hi_tot = hi_ok = 0
+    for j, nP in enumerate(g['listDoG']):
+        p0 = g['trial_p0'][:, j, :nP]
+        popt, pcov, chi, status, nfev = ctx.expfit(t, y, dy, p0, tau_max)
+        K = nP // 2
+        for i in range(nres):
+            ref_ok = bool(g['trial_quality'][i, j, 0])
+            assert (status[i] > 0) == ref_ok or nP >= 7
+            if not ref_ok or status[i] <= 0:
+                continue
+            rel = abs(chi[i] / g['trial_chi'][i, j] - 1)
+            assert np.all(popt[i, :K] >= 0) and np.all(popt[i, :K] <= 1) and np.all(popt[i, K:2 * K] <= tau_max)
+            if nP <= 5:
+                lo_tot += 1
+                lo_ok += rel < 1e-4
+            else:
+                hi_tot += 1
+                hi_ok += rel < 5e-2
+    print('%s: <=5 params %d/%d within 1e-4;  7-9 params %d/%d within 5e-2' % (tag, lo_ok, lo_tot, hi_ok, hi_tot))
+    assert lo_ok >= 0.97 * lo_tot
+    assert hi_ok >= 0.85 * hi_tot
+
+
+def test_device_fit_failure_modes(ctx):
+    """p0 outside the bounds -> scipy raises ValueError, the reference marks the fit failed
+    (fitting_Ct_functions.py:325-328); NaN data -> residuals not finite."""
+    t = np.arange(1, 51) * 10.0
+    y = 0.8 + 0.2 * np.exp(-t / 100.0)
+    popt, pcov, chi, status, nfev = ctx.expfit(t, np.stack([y, y]), None, [[0.2, 100.0, 1.5], [0.2, 100.0, 0.8]], 5000.0)
+    assert status[0] == -2 and np.isinf(chi[0])
+    assert status[1] > 0 and abs(popt[1, 2] - 0.8) < 1e-6 and abs(popt[1, 1] - 100.0) < 1e-3
+    yy = y.copy()
+    yy[3] = np.nan
+    _, _, chi, status, _ = ctx.expfit(t, yy[None], None, [[0.2, 100.0, 0.8]], 5000.0)
+    assert status[0] == -3

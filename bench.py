@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--workload', type=str, default='cfg3', choices=['cfg2', 'cfg3'])
     ap.add_argument('--vectors', type=int, default=None, help='vectors per GPU (default: the config value)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--stage-breakdown', action='store_true', help='after the timed loop, print a synchronised per-stage wall-time breakdown to stderr (diagnostic)')
     ap.add_argument('--cpu-sample-vectors', type=int, default=8)
     return ap.parse_args()
 
@@ -164,6 +165,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+
+    if args.stage_breakdown and rank == 0:
+        with torch.cuda.stream(stream):
+            names = ['pack', 'ct', 'hist', 'fit', 'relax']
+            fns = [lambda: pipe.stage_pack(vecs), pipe.stage_ct, pipe.stage_hist, pipe.stage_fit, pipe.stage_relax]
+            acc = {n: 0.0 for n in names}
+            for _ in range(3):
+                for n, fn in zip(names, fns):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize()
+                    acc[n] += (time.perf_counter() - t1) / 3
+            print('stage wall ms:', {k: round(v * 1e3, 3) for k, v in acc.items()}, 'fit nfev total', pipe.nfev_total, file=sys.stderr)
+            for nP, nf in pipe.nfev_last.items():
+                print('  order %d: %d fits, nfev mean %.1f median %d p95 %d max %d, >=%d: %d' % (nP, nf.size, nf.mean(), np.median(nf), np.percentile(nf, 95), nf.max(), 100 * nP, int((nf >= 100 * nP).sum())), file=sys.stderr)
 
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)

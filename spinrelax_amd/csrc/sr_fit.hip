@@ -16,9 +16,12 @@
 // matrix B = (J d)^T (J d) + diag_h is Cholesky-factorised for every Levenberg parameter alpha that
 // More's iteration visits -- phi(alpha) and phi'(alpha) are the same functions, evaluated differently.
 //
-// Mapping: one wave (64 lanes) per residue.  The L data points are spread over the lanes for model
-// evaluation and the J^T J / J^T f reductions; the n <= 11 dimensional algebra is wave-uniform and
-// held in registers (the kernel is templated on n so every small array is statically indexed).
+// Mapping: one workgroup of W = 4 waves (one per SIMD of a CU) per residue.  The L data points are spread over the
+// W*64 threads for model evaluation and the J^T J / J^T f reductions (wave shuffles, then a fixed-order
+// combine through LDS); the n <= 11 dimensional algebra is workgroup-uniform, executed redundantly by
+// every thread and held in registers (the kernel is templated on n so every small array is statically
+// indexed).  The critical path of a fit is serial (up to 100 n dependent iterations), so the kernel is
+// latency-bound by design: the W waves exist to shorten each iteration, not to raise throughput.
 #include "sr_internal.h"
 
 namespace {
@@ -38,12 +41,7 @@ struct FitArgs {
     double *fws;                      // (nRes, 2, L) residual work space
 };
 
-__device__ __forceinline__ double wsum(double v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
+__device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 
 // ---- model: curvefit_exponential, fitting_Ct_functions.py:419-427 -----------------------------
 template <int N>
@@ -120,11 +118,15 @@ __device__ __forceinline__ double bilinN(const double *B, const double *u, const
     return q;
 }
 
-// Cholesky of (B + alpha I) into Lf (packed lower).  Returns false when a pivot is not positive.
+// Cholesky of (B + alpha I): Lf holds the strict lower triangle of L, inv[i] = 1/L_ii (the factor is only
+// ever used through multiplications by these reciprocals: one rsqrt per column instead of a sqrt and
+// n divisions -- float64 sqrt/div are ~15-instruction dependent chains and dominated the serial part).
+// Returns false when a pivot is not positive; lmin2 = smallest squared diagonal of L.
 template <int N>
-__device__ __forceinline__ bool cholN(const double *B, double alpha, double *Lf)
+__device__ __forceinline__ bool cholN(const double *B, double alpha, double *Lf, double *inv, double &lmin2)
 {
     bool ok = true;
+    lmin2 = 1e300;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
 #pragma unroll
@@ -134,9 +136,10 @@ __device__ __forceinline__ bool cholN(const double *B, double alpha, double *Lf)
             for (int k = 0; k < j; ++k) s -= Lf[tri(i, k)] * Lf[tri(j, k)];
             if (i == j) {
                 if (!(s > 0.0)) { ok = false; s = 1.0; }
-                Lf[tri(i, i)] = sqrt(s);
+                lmin2 = fmin(lmin2, s);
+                inv[i] = rsqrt(s);
             } else {
-                Lf[tri(i, j)] = s / Lf[tri(j, j)];
+                Lf[tri(i, j)] = s * inv[j];
             }
         }
     }
@@ -144,26 +147,26 @@ __device__ __forceinline__ bool cholN(const double *B, double alpha, double *Lf)
 }
 // solve L z = b (forward)
 template <int N>
-__device__ __forceinline__ void fwdN(const double *Lf, const double *b, double *z)
+__device__ __forceinline__ void fwdN(const double *Lf, const double *inv, const double *b, double *z)
 {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         double s = b[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= Lf[tri(i, k)] * z[k];
-        z[i] = s / Lf[tri(i, i)];
+        z[i] = s * inv[i];
     }
 }
 // solve L^T p = z (backward)
 template <int N>
-__device__ __forceinline__ void bwdN(const double *Lf, const double *z, double *p)
+__device__ __forceinline__ void bwdN(const double *Lf, const double *inv, const double *z, double *p)
 {
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
         double s = z[i];
 #pragma unroll
         for (int k = i + 1; k < N; ++k) s -= Lf[tri(k, i)] * p[k];
-        p[i] = s / Lf[tri(i, i)];
+        p[i] = s * inv[i];
     }
 }
 
@@ -171,20 +174,18 @@ __device__ __forceinline__ void bwdN(const double *Lf, const double *z, double *
 // (common.py:phi_and_derivative expressed through the Cholesky factor: with L L^T = B + alpha I,
 //  z = L^-1 g, p = -L^-T z, q = L^-1 p:  p^T (B+alpha I)^-1 p = ||q||^2.)
 template <int N>
-__device__ __forceinline__ bool phiN(const double *B, const double *g, double alpha, double Delta, double *p,
-                                     double &phi, double &phi_prime)
+__device__ __forceinline__ void phi_from_factor(const double *Lf, const double *inv, const double *g, double Delta,
+                                                double *p, double &phi, double &phi_prime)
 {
-    double Lf[N * (N + 1) / 2], z[N], q[N];
-    const bool ok = cholN<N>(B, alpha, Lf);
-    fwdN<N>(Lf, g, z);
-    bwdN<N>(Lf, z, p);
+    double z[N], q[N];
+    fwdN<N>(Lf, inv, g, z);
+    bwdN<N>(Lf, inv, z, p);
 #pragma unroll
     for (int i = 0; i < N; ++i) p[i] = -p[i];
-    fwdN<N>(Lf, p, q);
+    fwdN<N>(Lf, inv, p, q);
     const double pn = normN<N>(p);
     phi = pn - Delta;
     phi_prime = -dotN<N>(q, q) / pn;
-    return ok;
 }
 
 // common.py:solve_lsq_trust_region
@@ -194,37 +195,29 @@ __device__ void solve_tr(const double *B, const double *g, int m, double Delta, 
     // rank test of scipy: s_min > EPS*m*s_max on the singular values of the augmented Jacobian.  Here:
     // B is accepted as full rank when its Cholesky factorisation succeeds with pivots above the
     // equivalent threshold (EPS*m)^2 * max diag.
-    double Lf[N * (N + 1) / 2], z[N];
-    bool full_rank = cholN<N>(B, 0.0, Lf);
+    double Lf[N * (N + 1) / 2], inv[N], lmin2;
+    bool full_rank = cholN<N>(B, 0.0, Lf, inv, lmin2);
     if (full_rank) {
-        double dmax = 0.0, lmin = 1e300;
+        double dmax = 0.0;
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            dmax = fmax(dmax, B[tri(i, i)]);
-            lmin = fmin(lmin, Lf[tri(i, i)]);
-        }
+        for (int i = 0; i < N; ++i) dmax = fmax(dmax, B[tri(i, i)]);
         const double thr = kEPS * (double)m;
-        if (!(lmin * lmin > thr * thr * dmax)) full_rank = false;
-    }
-    if (full_rank) {
-        fwdN<N>(Lf, g, z);
-        bwdN<N>(Lf, z, p);
-#pragma unroll
-        for (int i = 0; i < N; ++i) p[i] = -p[i];
-        if (normN<N>(p) <= Delta) { alpha = 0.0; return; }
+        if (!(lmin2 > thr * thr * dmax)) full_rank = false;
     }
     double alpha_upper = normN<N>(g) / Delta;
     double alpha_lower = 0.0;
     if (full_rank) {
         double phi, phip;
-        phiN<N>(B, g, 0.0, Delta, p, phi, phip);
+        phi_from_factor<N>(Lf, inv, g, Delta, p, phi, phip);     // p = Gauss-Newton step
+        if (phi <= 0.0) { alpha = 0.0; return; }                 // norm(p) <= Delta
         alpha_lower = -phi / phip;
     }
     if (!full_rank && alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
     for (int it = 0; it < 10; ++it) {
         if (alpha < alpha_lower || alpha > alpha_upper) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
         double phi, phip;
-        phiN<N>(B, g, alpha, Delta, p, phi, phip);
+        cholN<N>(B, alpha, Lf, inv, lmin2);
+        phi_from_factor<N>(Lf, inv, g, Delta, p, phi, phip);
         if (phi < 0) alpha_upper = alpha;
         const double ratio = phi / phip;
         alpha_lower = fmax(alpha_lower, alpha - ratio);
@@ -232,10 +225,12 @@ __device__ void solve_tr(const double *B, const double *g, int m, double Delta, 
         if (fabs(phi) < 0.01 * Delta) break;
     }
     {
-        double phi, phip;
-        phiN<N>(B, g, alpha, Delta, p, phi, phip);
+        double z[N];
+        cholN<N>(B, alpha, Lf, inv, lmin2);
+        fwdN<N>(Lf, inv, g, z);
+        bwdN<N>(Lf, inv, z, p);
     }
-    const double sc = Delta / normN<N>(p);
+    const double sc = -Delta / normN<N>(p);
 #pragma unroll
     for (int i = 0; i < N; ++i) p[i] *= sc;
 }
@@ -401,23 +396,45 @@ __device__ __forceinline__ void strictly_feasible(double *x, const double *lb, c
     }
 }
 
-template <int N>
+template <int N, int W>
 struct Trf {
     static constexpr int K = N / 2;
     static constexpr int NT = N * (N + 1) / 2;
+    static constexpr int NTH = W * 64;
     using M = Model<N>;
 
     const double *t, *y, *sg;
-    int L, lane;
+    int L, tid;
+    double *red;          // LDS: W x (NT + N + 2) partials
+
+    // sum of v over the workgroup, identical in every thread (fixed combination order)
+    template <int CNT>
+    __device__ __forceinline__ void block_sums(double *vals) const
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) {
+            const double w = wsum(vals[k]);
+            if (lane == 0) red[wave * (NT + N + 2) + k] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) {
+            double acc = red[k];
+#pragma unroll
+            for (int w = 1; w < W; ++w) acc += red[w * (NT + N + 2) + k];
+            vals[k] = acc;
+        }
+        __syncthreads();
+    }
 
     __device__ __forceinline__ double weight(int l) const { return sg ? 1.0 / sg[l] : 1.0; }
 
     // residuals f = w*(model - y) into out; returns cost = 0.5 f.f ; finite=false when any f is not finite
     __device__ double eval_f(const double *x, double *out, bool &finite) const
     {
-        double acc = 0.0;
-        int bad = 0;
-        for (int l = lane; l < L; l += 64) {
+        double acc = 0.0, bad = 0.0;
+        for (int l = tid; l < L; l += NTH) {
             double e[K > 0 ? K : 1];
             M::exps(x, t[l], e);
             double f;
@@ -426,11 +443,12 @@ struct Trf {
                 f = weight(l) * (M::value(x, e) - y[l]);
             }
             out[l] = f;
-            bad |= !isfinite(f);
-            acc += f * f;
+            if (!isfinite(f)) bad = 1.0; else acc += f * f;
         }
-        finite = __ballot(bad) == 0ull;
-        return 0.5 * wsum(acc);
+        double v[2] = {acc, bad};
+        block_sums<2>(v);
+        finite = v[1] == 0.0;
+        return 0.5 * v[0];
     }
 
     // J^T J (packed) and J^T f for the residual vector f0 stored in fbuf
@@ -457,7 +475,7 @@ struct Trf {
         for (int i = 0; i < NT; ++i) Aacc[i] = 0.0;
 #pragma unroll
         for (int i = 0; i < N; ++i) gacc[i] = 0.0;
-        for (int l = lane; l < L; l += 64) {
+        for (int l = tid; l < L; l += NTH) {
             const double tl = t[l], w = weight(l), f0 = fbuf[l];
             double e[K > 0 ? K : 1], Jr[N];
             M::exps(x, tl, e);
@@ -498,24 +516,32 @@ struct Trf {
                 for (int j = 0; j <= i; ++j) Aacc[tri(i, j)] += Jr[i] * Jr[j];
             }
         }
+        double all[NT + N];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) A[i] = wsum(Aacc[i]);
+        for (int i = 0; i < NT; ++i) all[i] = Aacc[i];
 #pragma unroll
-        for (int i = 0; i < N; ++i) g[i] = wsum(gacc[i]);
+        for (int i = 0; i < N; ++i) all[NT + i] = gacc[i];
+        block_sums<NT + N>(all);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) A[i] = all[i];
+#pragma unroll
+        for (int i = 0; i < N; ++i) g[i] = all[NT + i];
     }
 };
 
-template <int N>
-__global__ __launch_bounds__(64) void k_trf(FitArgs a)
+template <int N, int W>
+__global__ __launch_bounds__(W * 64) void k_trf(FitArgs a)
 {
     constexpr int K = N / 2;
     constexpr int NT = N * (N + 1) / 2;
+    __shared__ double red_lds[W * (NT + N + 2)];
     const int res = blockIdx.x;
     if (a.skip && a.skip[res]) return;
-    const int lane = threadIdx.x;
-    Trf<N> T;
+    const int tid = threadIdx.x;
+    Trf<N, W> T;
     T.L = a.L;
-    T.lane = lane;
+    T.tid = tid;
+    T.red = red_lds;
     T.t = a.t + (int64_t)res * a.L;
     T.y = a.y + (int64_t)res * a.L;
     T.sg = a.sigma ? a.sigma + (int64_t)res * a.L : nullptr;
@@ -648,15 +674,15 @@ __global__ __launch_bounds__(64) void k_trf(FitArgs a)
     double pc[NT];
     bool cov_ok = false;
     if (have_fit && m > N) {
-        double Lf[NT];
-        cov_ok = cholN<N>(A, 0.0, Lf);
+        double Lf[NT], inv[N], lmin2;
+        cov_ok = cholN<N>(A, 0.0, Lf, inv, lmin2);
         if (cov_ok) {
             // conditioning guard equivalent to scipy's singular-value cut eps*max(m,n)*s_max
-            double dmax = 0.0, lmin = 1e300;
+            double dmax = 0.0;
 #pragma unroll
-            for (int i = 0; i < N; ++i) { dmax = fmax(dmax, A[tri(i, i)]); lmin = fmin(lmin, Lf[tri(i, i)]); }
+            for (int i = 0; i < N; ++i) dmax = fmax(dmax, A[tri(i, i)]);
             const double thr = kEPS * (double)m;
-            if (!(lmin * lmin > thr * thr * dmax)) cov_ok = false;
+            if (!(lmin2 > thr * thr * dmax)) cov_ok = false;
         }
         if (cov_ok) {
             const double s_sq = 2.0 * cost / (double)(m - N);
@@ -665,8 +691,8 @@ __global__ __launch_bounds__(64) void k_trf(FitArgs a)
                 double e[N], z[N], col[N];
 #pragma unroll
                 for (int i = 0; i < N; ++i) e[i] = (i == c) ? 1.0 : 0.0;
-                fwdN<N>(Lf, e, z);
-                bwdN<N>(Lf, z, col);
+                fwdN<N>(Lf, inv, e, z);
+                bwdN<N>(Lf, inv, z, col);
 #pragma unroll
                 for (int i = c; i < N; ++i) pc[tri(i, c)] = col[i] * s_sq;
             }
@@ -675,16 +701,17 @@ __global__ __launch_bounds__(64) void k_trf(FitArgs a)
     double chi = INFINITY;
     if (have_fit) {
         // calc_chiSq, fitting_Ct_functions.py:272-276: mean((model - y)^2 / sigma)
-        double acc = 0.0;
-        for (int l = lane; l < a.L; l += 64) {
+        double acc[1] = {0.0};
+        for (int l = tid; l < a.L; l += W * 64) {
             double e[K > 0 ? K : 1];
             Model<N>::exps(x, T.t[l], e);
             const double r = Model<N>::value(x, e) - T.y[l];
-            acc += T.sg ? (r * r) / T.sg[l] : r * r;
+            acc[0] += T.sg ? (r * r) / T.sg[l] : r * r;
         }
-        chi = wsum(acc) / (double)a.L;
+        T.template block_sums<1>(acc);
+        chi = acc[0] / (double)a.L;
     }
-    if (lane == 0) {
+    if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < N; ++i) a.popt[(int64_t)res * N + i] = x[i];
 #pragma unroll
@@ -735,7 +762,10 @@ __global__ __launch_bounds__(256) void k_resjac(const double *__restrict__ t, co
 template <int N>
 int launch_trf(sr_ctx *ctx, const FitArgs &a)
 {
-    hipLaunchKernelGGL(k_trf<N>, dim3((unsigned)a.nRes), dim3(64), 0, ctx->stream, a);
+    // 4 waves = one per SIMD of a CU: the redundant serial algebra is VALU-issue bound, a second wave per
+    // SIMD doubles its time (measured at n = 9: 68 / 41 / 28 / 51 us per iteration for W = 1 / 2 / 4 / 8)
+    constexpr int W = 4;
+    hipLaunchKernelGGL((k_trf<N, W>), dim3((unsigned)a.nRes), dim3(W * 64), 0, ctx->stream, a);
     SR_HIP(hipGetLastError());
     return 0;
 }

@@ -59,3 +59,55 @@ static inline size_t sr_lds_limit(const sr_ctx *ctx)
 }
 
 static inline int64_t sr_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+#ifdef __HIPCC__
+// ---- wave-level float64 sum on the VALU only (DPP + readlane), no LDS round trips -----------------
+// __shfl_xor on a double compiles to two ds_bpermute_b32 per step (LDS crossbar, ~100 cycles of
+// dependent latency each); the fit kernel reduces 54 values per Jacobian and was parked on those waits
+// half of its life (rocprofv3: SQ_WAIT_ANY 51 %).  DPP moves are ordinary VALU instructions.
+__device__ __forceinline__ double sr_dpp_f64(double v, const int ctrl_sel)
+{
+    union { double d; int i[2]; } a, b;
+    a.d = v;
+    switch (ctrl_sel) {
+        case 0:  // quad_perm [1,0,3,2]
+            b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0xB1, 0xF, 0xF, true);
+            b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0xB1, 0xF, 0xF, true);
+            break;
+        case 1:  // quad_perm [2,3,0,1]
+            b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x4E, 0xF, 0xF, true);
+            b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x4E, 0xF, 0xF, true);
+            break;
+        case 2:  // row_half_mirror
+            b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x141, 0xF, 0xF, true);
+            b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x141, 0xF, 0xF, true);
+            break;
+        default:  // row_mirror
+            b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x140, 0xF, 0xF, true);
+            b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x140, 0xF, 0xF, true);
+            break;
+    }
+    return b.d;
+}
+
+__device__ __forceinline__ double sr_readlane_f64(double v, int lane)
+{
+    union { double d; int i[2]; } a, b;
+    a.d = v;
+    b.i[0] = __builtin_amdgcn_readlane(a.i[0], lane);
+    b.i[1] = __builtin_amdgcn_readlane(a.i[1], lane);
+    return b.d;
+}
+
+// sum over the 64 lanes of a wave, result identical in every lane; fixed association order
+__device__ __forceinline__ double sr_wave_sum_f64(double v)
+{
+    v += sr_dpp_f64(v, 0);
+    v += sr_dpp_f64(v, 1);
+    v += sr_dpp_f64(v, 2);
+    v += sr_dpp_f64(v, 3);            // every lane of a 16-lane row holds the row sum
+    const double r0 = sr_readlane_f64(v, 0), r1 = sr_readlane_f64(v, 16);
+    const double r2 = sr_readlane_f64(v, 32), r3 = sr_readlane_f64(v, 48);
+    return (r0 + r1) + (r2 + r3);
+}
+#endif

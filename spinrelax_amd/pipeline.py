@@ -61,6 +61,7 @@ class DevicePipeline:
         self.binvecs = hm.lambert_bin_vectors(self.edges)
         self.csa = csa
         self.nfev_total = 0
+        self.nfev_last = {}
 
     # ---- stages ----
     def stage_pack(self, vecs):
@@ -94,7 +95,9 @@ class DevicePipeline:
             dvar = torch.diagonal(pcov, dim1=1, dim2=2).cpu().numpy()[idx]
             chi = self.chi_dev.cpu().numpy()[idx]
             status = self.status_dev.cpu().numpy()[idx]
-            self.nfev_total += int(self.nfev_dev.cpu().numpy()[idx].sum())
+            nf = self.nfev_dev.cpu().numpy()[idx]
+            self.nfev_total += int(nf.sum())
+            self.nfev_last[nParams] = nf
             with np.errstate(invalid='ignore'):
                 dP = np.sqrt(dvar)
             return popt, dP, chi, status

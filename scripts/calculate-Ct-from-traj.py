@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""
+Drop-in for the reference's calculate-Ct-from-traj.py (run-all.bash:476-481): same flags, same output
+files (<o>_Ctext.dat, <o>_Ctint.dat, <o>_vecHistogram.npz | _vecPhiTheta.npz|.dat, <o>_avgvec.dat,
+<o>_S2.dat).  C(t), the rotation into the PAF, the spherical histogram, the mean vector and S2 are
+computed on the MI355X (libspinrelax_hip.so); this script only parses arguments and moves files.
+
+Trajectory input:
+  * with MDTraj installed: -s <pdb> -f <xtc ...> exactly like the reference (vector extraction and
+    superposition are MDTraj's; reference lines 64-86, 402-491);
+  * without MDTraj (or for synthetic data): -f <file.npz|.npy> holding unit vectors of shape
+    (frames, bonds, 3) float32.  An .npz may carry `vecs` (body frame, required), `vecs_lab` (lab frame
+    for _Ctext.dat; defaults to `vecs`), `names` (resSeq per bond; default 2..V+1) and `dt` (ps; default
+    --dt).  -s is still parsed and ignored in that case.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spinrelax_amd import ct as hostct                      # noqa: E402
+from spinrelax_amd import general_scripts as gs             # noqa: E402
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description='Obtain the unit X-H vectors from one of more trajectories, and compute '
+                                            'S^2, C(t) and the vector distribution on the GPU (Palmer memory-time chunks).',
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument('-s', type=str, dest='topfn', required=True, nargs='+', help='Topology PDB (reference frame for fits).')
+    p.add_argument('-f', '--infn', type=str, dest='infn', required=True, nargs='+',
+                   help='One or more trajectories, or .npy/.npz files of precomputed unit vectors.')
+    p.add_argument('-o', '--outpref', type=str, dest='out_pref', default='out', help='Output file prefix.')
+    p.add_argument('--split', type=int, dest='nSplitFrames', default=-1, help='Read trajectories in chunks of N frames (MDTraj input).')
+    p.add_argument('-t', '--tau', type=float, dest='tau', default=None, help='Memory time (global tumbling estimate), same units as the trajectory.')
+    p.add_argument('--prefact', type=float, dest='zeta', default=(1.02 / 1.04) ** 6, help='Zero-point vibration prefactor applied to S2 output.')
+    p.add_argument('--S2', dest='bDoS2', action='store_true', default=False, help='Calculate order parameters S2.')
+    p.add_argument('--Ct', dest='bDoCt', action='store_true', default=False, help='Calculate autocorrelation C(t).')
+    p.add_argument('--vecDist', dest='bDoVecDistrib', action='store_true', default=False, help='Print the vector distribution in spherical coordinates.')
+    p.add_argument('--binary', action='store_true', default=False, help='Numpy binary storage for the vector distribution.')
+    p.add_argument('--vecHist', dest='bDoVecHist', action='store_true', default=False, help='Print the 2D histogram instead of all vectors.')
+    p.add_argument('--histBin', type=int, default=72, help='Number of bins along phi; theta uses half this number.')
+    p.add_argument('--vecAvg', dest='bDoVecAverage', action='store_true', default=False, help='Print the average unit XH-vector.')
+    p.add_argument('--vecRot', dest='vecRotQ', type=str, default='', help='Rotation quaternion "w x y z" into the PAF frame.')
+    p.add_argument('--Hsel', '--selection', type=str, dest='Hseltxt', default='name H', help='MDTraj selection of the H atoms.')
+    p.add_argument('--Xsel', type=str, dest='Xseltxt', default='name N and not resname PRO', help='MDTraj selection of the X atoms.')
+    p.add_argument('--fitsel', type=str, dest='fittxt', default='custom occupancy', help='MDTraj selection used for the superposition.')
+    p.add_argument('--help_sel', action='store_true', help='Display help for selection texts and exit.')
+    p.add_argument('--dt', type=float, default=10.0, help='[extension] frame spacing in ps for .npy vector input.')
+    p.add_argument('--exact', action='store_true', help='[extension] float64 validation mode of the C(t) kernel.')
+    return p
+
+
+def load_vector_files(files, default_dt):
+    """.npy / .npz vector input -> (resXH, [vecXH per file], [vecXHfit per file], deltaT)."""
+    resXH, lab, body, dt = None, [], [], None
+    for fn in files:
+        if fn.endswith('.npy'):
+            v = np.load(fn)
+            names, vl, d = None, v, default_dt
+        else:
+            z = np.load(fn, allow_pickle=True)
+            v = z['vecs']
+            vl = z['vecs_lab'] if 'vecs_lab' in z else v
+            names = list(z['names']) if 'names' in z else None
+            d = float(z['dt']) if 'dt' in z else default_dt
+        if v.ndim != 3 or v.shape[2] != 3:
+            print("= = = ERROR: vector file %s does not hold a (frames, bonds, 3) array!" % fn, file=sys.stderr)
+            sys.exit(1)
+        names = list(range(2, v.shape[1] + 2)) if names is None else [int(x) for x in names]
+        if resXH is None:
+            resXH, dt = names, d
+        elif dt != d or resXH != names:
+            print("= = = ERROR: Differences in trajectories have been detected! Aborting.", file=sys.stderr)
+            sys.exit(1)
+        body.append(np.ascontiguousarray(v, dtype=np.float32))
+        lab.append(np.ascontiguousarray(vl, dtype=np.float32))
+    return resXH, lab, body, dt
+
+
+def load_mdtraj(args):
+    """The reference's loader (calculate-Ct-from-traj.py:396-498) on top of MDTraj."""
+    try:
+        import mdtraj as md
+    except ImportError:
+        print("= = = ERROR: MDTraj is not installed; give precomputed vectors as .npy/.npz to -f instead.", file=sys.stderr)
+        sys.exit(1)
+
+    def xh(traj):
+        iX = traj.topology.select(args.Xseltxt)
+        iH = traj.topology.select(args.Hseltxt)
+        if len(iX) == 0 or len(iH) == 0 or len(iX) != len(iH):
+            print("= = = ERROR: selection text failed to find matching atoms! N(%s) = %i , N(%s) = %i"
+                  % (args.Xseltxt, len(iX), args.Hseltxt, len(iH)), file=sys.stderr)
+            sys.exit(1)
+        v = np.take(traj.xyz, iH, axis=1) - np.take(traj.xyz, iX, axis=1)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            return np.nan_to_num(v / np.linalg.norm(v, axis=2)[..., None]).astype(np.float32)
+
+    def fit_indices(ref, fn):
+        if args.fittxt == 'custom occupancy':
+            pdb = md.formats.pdb.pdbstructure.PdbStructure(open(fn))
+            mask = [a.get_occupancy() for a in pdb.iter_atoms()]
+            inds = ref.topology.select('all')
+            return [inds[i] for i in range(len(mask)) if mask[i] > 0.0]
+        return ref.topology.select(args.fittxt)
+
+    resXH, lab, body, dt = None, [], [], None
+    for i, fn in enumerate(args.infn):
+        top = args.topfn[i] if len(args.topfn) > 1 else args.topfn[0]
+        ref = md.load(top)
+        fi = fit_indices(ref, top)
+        chunks = md.iterload(fn, chunk=1000, top=top) if args.nSplitFrames > 0 else [md.load(fn, top=top)]
+        l, b = [], []
+        for trj in chunks:
+            names = [trj.topology.atom(k).residue.resSeq for k in trj.topology.select(args.Hseltxt)]
+            d = trj.timestep
+            l.append(xh(trj))
+            trj.center_coordinates()
+            trj.superpose(ref, frame=0, atom_indices=fi)
+            b.append(xh(trj))
+        if resXH is None:
+            resXH, dt = names, d
+        lab.append(np.concatenate(l, axis=0))
+        body.append(np.concatenate(b, axis=0))
+    return resXH, lab, body, dt
+
+
+def main():
+    args = build_parser().parse_args()
+    time_start = time.time()
+    if args.help_sel:
+        print("Notes: This program uses MDTraj selection syntax, e.g. 'chain A and resname GLY and name HA1 HA2'.")
+        sys.exit(0)
+    tau_memory = args.tau
+    if args.bDoCt and tau_memory is None:
+        print("= = = Refusing to do C(t)-analysis without using a block averaging over memory_time tau!", file=sys.stderr)
+        sys.exit(1)
+    bDoVecDistrib = args.bDoVecDistrib or args.bDoVecHist
+    q_rot = None
+    if args.vecRotQ != '':
+        q_rot = np.array([float(v) for v in args.vecRotQ.split()])
+        if len(q_rot) != 4 or not np.allclose(np.dot(q_rot, q_rot), 1):
+            print("= = = ERROR: input rotation quaternion is malformed!", q_rot)
+            sys.exit(23)
+    if len(args.topfn) > 1 and len(args.topfn) != len(args.infn):
+        print("= = ERROR: When giving multiple reference files, you must have one for each trajecfile file given!", file=sys.stderr)
+        sys.exit(1)
+
+    if all(f.endswith('.npy') or f.endswith('.npz') for f in args.infn):
+        resXH, vecXH, vecXHfit, deltaT = load_vector_files(args.infn, args.dt)
+    else:
+        resXH, vecXH, vecXHfit, deltaT = load_mdtraj(args)
+    if tau_memory is not None and deltaT > 0.5 * tau_memory:
+        print("= = = ERROR: delta-t form the trajectory is too small relative to tau! %g vs. %g" % (deltaT, tau_memory), file=sys.stderr)
+        sys.exit(1)
+    print("= = Loading finished.")
+    out_pref = args.out_pref
+
+    if tau_memory is not None:
+        F = int(tau_memory / deltaT)
+        print("= = Reformatting all vecXH information into chunks of tau ( %g ) " % tau_memory)
+        print("    ...debug: Using %i frames per chunk based on tau/dt (%g/%g)." % (F, tau_memory, deltaT))
+        used = [v[: (v.shape[0] // F) * F] for v in vecXHfit]          # reformat_vecs_by_tau drops each file's tail
+        vec3d = used[0] if len(used) == 1 else np.concatenate(used, axis=0)
+    else:
+        F = None
+        vec3d = vecXHfit[0] if len(vecXHfit) == 1 else np.concatenate(vecXHfit, axis=0)
+
+    if args.bDoCt:
+        mode = 1 if args.exact else 0
+        dt = hostct.calculate_dt(deltaT, tau_memory)
+        print("= = = Conducting Ct_external using Palmer's approach.")
+        print("= = = timestep: ", deltaT, "ps")
+        print("= = = tau_memory: ", tau_memory, "ps")
+        Ct, dCt = hostct.calculate_Ct_from_files(vecXH, deltaT, tau_memory, mode=mode)
+        gs.print_sxylist(out_pref + '_Ctext.dat', resXH, dt, np.stack((Ct.T, dCt.T), axis=-1))
+        print("= = = Conducting Ct_internal using Palmer's approach.")
+        Ct, dCt = hostct.calculate_Ct_from_files(vecXHfit, deltaT, tau_memory, mode=mode)
+        gs.print_sxylist(out_pref + '_Ctint.dat', resXH, dt, np.stack((Ct.T, dCt.T), axis=-1))
+    del vecXH
+
+    need_dist = args.bDoVecAverage or args.bDoS2 or (bDoVecDistrib and args.bDoVecHist)
+    if need_dist:
+        if q_rot is not None:
+            print("= = = Rotating all fitted vectors by the input quaternion into PAF.")
+        dist = hostct.vector_distribution(vec3d, q_rot, histBinX=args.histBin,
+                                          delta_t=deltaT if tau_memory is not None else -1,
+                                          tau_memory=tau_memory if tau_memory is not None else -1)
+    if args.bDoVecAverage:
+        gs.print_xylist(out_pref + '_avgvec.dat', resXH, np.array(dist['avgvec']).T, True)
+    if bDoVecDistrib:
+        print("= = = Converting vectors into spherical coordinates.")
+        if not args.bDoVecHist:
+            # full (phi, theta) listing: rotation on the GPU, the two angle maps are plain numpy ufuncs
+            rot = hostct.rotate_vector_simd(vec3d, q_rot) if q_rot is not None else vec3d
+            r = np.linalg.norm(rot, axis=-1)
+            pt = np.stack((np.arctan2(rot[..., 1], rot[..., 0]), np.arccos(rot[..., 2] / r)), axis=-1)
+            pt = np.transpose(pt, axes=(1, 0, 2))
+            if args.binary:
+                gs.save_vecPhiTheta_npz(out_pref + '_vecPhiTheta.npz', resXH, pt)
+            else:
+                rtp = np.concatenate((np.transpose(r)[..., None], pt), axis=-1)
+                gs.print_s3d(out_pref + '_vecPhiTheta.dat', resXH, rtp, (1, 2))
+        else:
+            print("= = = Histgrams will use Lambert Cylindrical projection by converting Theta spanning (0,pi) to cos(Theta) spanning (-1,1)")
+            if args.binary:
+                gs.save_vecHistogram_npz(out_pref + '_vecHistogram.npz', resXH, dist['hist'], dist['edges'])
+            else:
+                for i in range(len(resXH)):
+                    ofile = out_pref + '_vecXH_' + str(resXH[i]) + '.hist'
+                    gs.print_gplot_hist(ofile, dist['hist'][i], dist['edges'],
+                                        header='# Lamber Cylindrical Histogram over phi,cos(theta).', bSphere=True)
+                    print("= = = Written to output: ", ofile)
+    if args.bDoS2:
+        if tau_memory is not None:
+            print("= = = Conducting S2 analysis using memory time to chop input-trajectories", tau_memory, "ps")
+        else:
+            print("= = = Conducting S2 analysis directly from trajectories.")
+        S2 = dist['S2']
+        gs.print_xylist(out_pref + '_S2.dat', resXH, (S2.T) * args.zeta, True)
+        print("      ...complete.")
+    print("= = Finished. Total seconds elapsed: %g" % (time.time() - time_start))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,192 @@
+"""
+Text / numpy file formats at the drop-in boundary: the files run-all.bash passes
+between the steps of the workflow.  Writers produce byte-identical text to the reference's
+general_scripts.py for the same arrays (tests/test_formats.py compares against files written by the
+reference itself); readers accept what the reference's writers produce.
+
+Reference: general_scripts.py:11-16, 47-67, 182-290; calculate-Ct-from-traj.py:604-630.
+"""
+import sys
+
+import numpy as np
+
+
+def normalise_vector_array(v):
+    """general_scripts.py:11-16."""
+    return v / np.sqrt((v ** 2).sum(-1))[..., np.newaxis]
+
+
+def _is_data(line):
+    return not (line == "" or line[0] in "#@&" or line[0] == "\n")
+
+
+def load_xy(fn):
+    """general_scripts.py:47-56: two-column file, comment / xmgrace lines skipped."""
+    x, y = [], []
+    for l in open(fn):
+        if not _is_data(l):
+            continue
+        w = l.split()
+        x.append(float(w[0]))
+        y.append(float(w[1]))
+    return np.array(x), np.array(y)
+
+
+def load_xys(fn):
+    """general_scripts.py:58-67: first column x, remaining columns y."""
+    x, y = [], []
+    for l in open(fn):
+        if l == "" or l[0] in "#@&" or l.strip() == "":
+            continue
+        v = [float(i) for i in l.split()]
+        x.append(v[0])
+        y.append(v[1:])
+    return np.array(x), np.array(y)
+
+
+def load_sxydylist(fn, key="legend"):
+    """general_scripts.py:182-213: xmgrace multi-set file with `@s<i> legend "<name>"` lines; sets end at '&'.
+    Returns (legends, x[nset, npts], y, dy) -- dy is [] when the file has no third column."""
+    legs, xs, ys, dys = [], [], [], []
+    x, y, dy = [], [], []
+    for l in open(fn):
+        if l == "" or l == "\n":
+            continue
+        w = l.split()
+        if l[0] == "#" or l[0] == "@":
+            if key in l:
+                legs.append(w[-1].strip('"'))
+            continue
+        if l[0] == "&":
+            xs.append(x)
+            ys.append(y)
+            if len(dy) > 0:
+                dys.append(dy)
+            x, y, dy = [], [], []
+            continue
+        x.append(float(w[0]))
+        y.append(float(w[1]))
+        if len(w) > 2:
+            dy.append(float(w[2]))
+    if x != []:
+        xs.append(x)
+        ys.append(y)
+        dys.append(dy)
+    if dys != []:
+        return legs, np.array(xs), np.array(ys), np.array(dys)
+    return legs, np.array(xs), np.array(ys), []
+
+
+def print_xy(fn, x, y, dy=None, header=""):
+    """general_scripts.py:231-244: `print(x[i], y[i][, dy[i]])` per line, i.e. the str() of the numpy
+    scalars (float32 for the relaxation datablock).  dy=None/empty -> two columns."""
+    with open(fn, 'w') as fp:
+        if header != "":
+            print(header, file=fp)
+        if dy is None or len(dy) == 0:
+            for i in range(len(x)):
+                print(x[i], y[i], file=fp)
+        else:
+            for i in range(len(x)):
+                print(x[i], y[i], dy[i], file=fp)
+
+
+def print_xydy(fn, x, y, dy, header=""):
+    print_xy(fn, x, y, dy, header)
+
+
+def print_xylist(fn, x, ylist, bCols=False, header=""):
+    """general_scripts.py:246-273 (x(nvals), y(nplots, nvals); bCols stacks the plots as columns, %g)."""
+    ylist = np.array(ylist)
+    with open(fn, 'w') as fp:
+        if header != "":
+            print(header, file=fp)
+        if ylist.ndim == 1:
+            for j in range(len(x)):
+                print(x[j], ylist[j], file=fp)
+            print("&", file=fp)
+        elif ylist.ndim == 2:
+            nplot, nvals = ylist.shape
+            if bCols:
+                for j in range(nvals):
+                    print("%g " % x[j] + " ".join("%g" % ylist[i][j] for i in range(nplot)), file=fp)
+                print("&", file=fp)
+            else:
+                for i in range(nplot):
+                    for j in range(len(x)):
+                        print(x[j], ylist[i][j], file=fp)
+                    print("&", file=fp)
+
+
+def print_sxylist(fn, legend, x, ylist, header=[]):
+    """general_scripts.py:275-290 -- the `_Ctint.dat` / `_Ctext.dat` writer: per set `@s<i> legend "<name>"`,
+    then `x[j] <numpy str of ylist[i][j] without brackets>`, then `&`.  The numeric text is whatever numpy's
+    str() gives for the array dtype (8 significant digits), exactly like the reference."""
+    ylist = np.array(ylist)
+    with open(fn, 'w') as fp:
+        for line in header:
+            print("%s" % line, file=fp)
+        for i in range(len(ylist)):
+            print("@s%d legend \"%s\"" % (i, legend[i]), file=fp)
+            for j in range(len(x)):
+                print(x[j], str(ylist[i][j]).strip('[]'), file=fp)
+            print("&", file=fp)
+
+
+def print_s3d(fn, legend, arr, cols, header=[]):
+    """general_scripts.py:292-307 (text form of --vecDist)."""
+    with open(fn, 'w') as fp:
+        for line in header:
+            print("%s" % line, file=fp)
+        for i in range(arr.shape[0]):
+            print("@s%d legend \"%s\"" % (i, legend[i]), file=fp)
+            for j in range(arr.shape[1]):
+                print(" ".join("%g" % arr[i, j, c] for c in cols), file=fp)
+            print("&", file=fp)
+
+
+def print_gplot_hist(fn, hist, edges, header='', bSphere=False):
+    """general_scripts.py:327-381: gnuplot-style bin-centre listing (sphere completion rows when bSphere)."""
+    nbins = hist.shape
+    dim = len(nbins)
+    with open(fn, 'w') as fp:
+        if header != '':
+            print('%s' % header, file=fp)
+        print('# DIMENSIONS: %i' % dim, file=fp)
+        print("# BINWIDTH: " + " ".join("%g" % ((edges[i][-1] - edges[i][0]) / nbins[i]) for i in range(dim)), file=fp)
+        print("# NBINS: " + " ".join("%g" % (nbins[i]) for i in range(dim)), file=fp)
+        if bSphere:
+            if dim != 2:
+                print("= = = ERROR: histogram data is not in 2D, but spherical histogram plotting is requested!", file=sys.stderr)
+                sys.exit(1)
+            xmin = 0.5 * (edges[0][0] + edges[0][1])
+            ymin, ymax = edges[1][0], edges[1][-1]
+            rows = [(0.5 * (edges[0][eX] + edges[0][eX + 1]), hist[eX]) for eX in range(nbins[0])]
+            rows.append((xmin + 2 * np.pi, hist[0]))
+            for xavg, col in rows:
+                print('%g %g %g' % (xavg, ymin, col[0]), file=fp)
+                for eY in range(nbins[1]):
+                    print('%g %g %g' % (xavg, 0.5 * (edges[1][eY] + edges[1][eY + 1]), col[eY]), file=fp)
+                print('%g %g %g' % (xavg, ymax, col[-1]), file=fp)
+                print('', file=fp)
+        else:
+            for index, val in np.ndenumerate(hist):
+                s = " ".join("%g" % (0.5 * (edges[i][index[i]] + edges[i][index[i] + 1])) for i in range(dim))
+                print(s + " %g" % val, file=fp)
+                if index[-1] == nbins[-1] - 1:
+                    print('', file=fp)
+
+
+def save_vecHistogram_npz(fn, names, hist, edges):
+    """calculate-Ct-from-traj.py:629-630.  numpy >= 1.24 refuses the ragged `edges` list the reference
+    passes; it is stored as the object array older numpy built implicitly (readers use allow_pickle and
+    index edges[0], edges[1]: spectral_densities.py:285-292, 2338-2339)."""
+    e = np.empty(2, dtype=object)
+    e[0], e[1] = edges[0], edges[1]
+    np.savez_compressed(fn, names=names, dataType='LambertCylindrical', bHistogram=True, edges=e,
+                        axisLabels=['phi', 'cos(theta)'], data=hist)
+
+
+def save_vecPhiTheta_npz(fn, names, phitheta):
+    """calculate-Ct-from-traj.py:604-605."""
+    np.savez_compressed(fn, names=names, dataType='PhiTheta', axisLabels=['phi', 'theta'], bHistogram=False, data=phitheta)

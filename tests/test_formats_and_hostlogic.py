@@ -1,0 +1,197 @@
+"""
+CPU tests of the drop-in boundary and the host logic: the writers must reproduce, byte for byte, files the
+REFERENCE's own writers produced (tests/golden/*.dat, made by oracle/gen_golden.py); the readers must
+recover the reference's numbers; the vectorised model-order search must reproduce the reference's
+selection when fed the reference's own per-order fit results.  No GPU, no oracle compute.
+"""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, golden
+from spinrelax_amd import general_scripts as gs
+from spinrelax_amd import fitting_Ct_functions as fitCt
+from spinrelax_amd import _hostmath as hm
+from spinrelax_amd import ct as hostct
+from spinrelax_amd import dist as srdist
+
+
+def same(a, b):
+    assert filecmp.cmp(a, b, shallow=False), 'files differ: %s %s' % (a, b)
+
+
+def test_Ctint_writer_byte_exact(tmp_path):
+    g = golden('cfg1_ct.npz')
+    names = list(range(2, 34))
+    fn = str(tmp_path / 'f64.dat')
+    gs.print_sxylist(fn, names, g['t'], np.stack((g['Ct64'].T, g['dCt64'].T), axis=-1))
+    same(fn, os.path.join(GOLD, 'cfg1_Ctint_f64.dat'))
+    fn = str(tmp_path / 'f32.dat')
+    gs.print_sxylist(fn, names, g['t'], np.stack((g['Ct32'].T, g['dCt32'].T), axis=-1))
+    same(fn, os.path.join(GOLD, 'cfg1_Ctint.dat'))
+
+
+def test_Ctint_reader():
+    f = golden('cfg1_fit.npz')
+    legs, t, y, dy = gs.load_sxydylist(os.path.join(GOLD, 'cfg1_Ctint.dat'), 'legend')
+    assert [int(x) for x in legs] == list(f['names'])
+    np.testing.assert_array_equal(t, f['t'])
+    np.testing.assert_array_equal(y, f['y'])
+    np.testing.assert_array_equal(dy, f['dy'])
+
+
+def test_avgvec_S2_writers_byte_exact(tmp_path):
+    g = golden('cfg1_vec.npz')
+    names = list(range(2, 34))
+    fn = str(tmp_path / 'avg.dat')
+    gs.print_xylist(fn, names, np.array(g['avgvec']).T, True)
+    same(fn, os.path.join(GOLD, 'cfg1_avgvec.dat'))
+    fn = str(tmp_path / 's2.dat')
+    gs.print_xylist(fn, names, (g['S2_tau'].T) * (1.02 / 1.04) ** 6, True)
+    same(fn, os.path.join(GOLD, 'cfg1_S2.dat'))
+    # S2 from the per-block outer-product sums (what kernel 2 returns) equals the reference formula
+    dt = hostct.calculate_dt(10.0, 1000.0)
+    assert dt.shape == (50,) and dt[0] == 10.0 and dt[-1] == 500.0
+
+
+def _models_from_golden(f):
+    ac = fitCt.autoCorrelations()
+    ac.import_target_array(keys=list(f['names']), DeltaT=f['t'], Decay=f['y'], dDecay=f['dy'])
+    for i, k in enumerate(f['names']):
+        K, free = fitCt.split_nparams(int(f['sel_nParams'][i]))
+        m = ac.add_model(k)
+        m._load_fit(dict(nParams=int(f['sel_nParams'][i]), C=f['sel_C'][i, :K], tau=f['sel_tau'][i, :K], S2=f['sel_S2'][i],
+                         dC=f['sel_dC'][i, :K], dtau=f['sel_dtau'][i, :K], dS2=f['sel_dS2'][i], chiSq=f['sel_chi'][i]))
+    return ac
+
+
+def test_fittedCt_writer_byte_exact_and_reader(tmp_path):
+    f = golden('cfg1_fit.npz')
+    ac = _models_from_golden(f)
+    fn = str(tmp_path / 'fitted.dat')
+    ac.export(fn)
+    same(fn, os.path.join(GOLD, 'cfg1_fittedCt.dat'))
+    back = fitCt.read_fittedCt_parameters(os.path.join(GOLD, 'cfg1_fittedCt.dat'))
+    r = golden('cfg1_relax.npz')
+    S2, C, tau, K = back.get_params_as_arrays(Kmax=4)
+    np.testing.assert_array_equal(S2, r['S2'])
+    np.testing.assert_array_equal(C, r['C'])
+    np.testing.assert_array_equal(tau, r['tau'])
+    np.testing.assert_array_equal(K, r['nComps'])
+    assert [int(k) for k in back.model.keys()] == list(r['names'])
+    # %g keeps 6 significant digits: the file is a lossy view of the fit
+    assert np.max(np.abs(S2 / f['sel_S2'] - 1)) < 1e-5
+
+
+def test_relaxation_writers_byte_exact(tmp_path):
+    r = golden('cfg1_relax.npz')
+    names = [int(x) for x in r['names']]
+    hdr = "# Fixed Diso: %g ps^-1\n# Fixed zeta: %g a.u.\n# Fixed CSA: %g ppm\n# Fixed chi: %g a.u.\n" % (
+        3.7383e-5, 0.890023, -170e-6 * 1e6, 0.0)
+    b = r['sym_f32_1']
+    fn = str(tmp_path / 'R1.dat')
+    gs.print_xydy(fn, names, b[0, :, 0], b[0, :, 1], header=hdr)
+    same(fn, os.path.join(GOLD, 'cfg1_sym_R1.dat'))
+    fn = str(tmp_path / 'rho.dat')
+    gs.print_xydy(fn, names, b[3, :, 0], b[3, :, 1])
+    same(fn, os.path.join(GOLD, 'cfg1_sym_rho.dat'))
+    b = r['iso_f32_1']
+    fn = str(tmp_path / 'NOE.dat')
+    gs.print_xy(fn, names, b[2, :], header=hdr)
+    same(fn, os.path.join(GOLD, 'cfg1_iso_NOE.dat'))
+
+
+def test_vecHistogram_npz_roundtrip(tmp_path):
+    v = golden('cfg1_vec.npz')
+    r = golden('cfg1_relax.npz')
+    ref = np.load(os.path.join(GOLD, 'cfg1_vecHistogram.npz'), allow_pickle=True)
+    fn = str(tmp_path / 'h.npz')
+    edges = hostct.lambert_edges(72)
+    np.testing.assert_array_equal(edges[0], v['edges_phi'])
+    np.testing.assert_array_equal(edges[1], v['edges_cos'])
+    gs.save_vecHistogram_npz(fn, list(range(2, 34)), v['hist'].astype(np.float64), edges)
+    mine = np.load(fn, allow_pickle=True)
+    for k in ('names', 'dataType', 'bHistogram', 'axisLabels', 'data'):
+        np.testing.assert_array_equal(mine[k], ref[k])
+    np.testing.assert_array_equal(mine['edges'][0], ref['edges'][0])
+    np.testing.assert_array_equal(mine['edges'][1], ref['edges'][1])
+    np.testing.assert_array_equal(hm.lambert_bin_vectors(mine['edges']), r['binvecs'])
+    from spinrelax_amd import spectral_densities as sd
+    ids, vecs, w = sd.read_vector_distribution_from_file(fn)
+    np.testing.assert_array_equal(w, r['weights'])
+    np.testing.assert_array_equal(vecs[3], r['binvecs'])
+
+
+@pytest.mark.parametrize('tag', ['cfg1', 'cfg2', 'cfg3s'])
+def test_order_search_reproduces_reference_selection(tag):
+    """Feed the vectorised model-order search with the reference's own per-order results: the initial guesses
+    must be bit-identical to the reference's and the accept/reject sequence must pick the same model."""
+    f = golden('%s_fit.npz' % tag)
+    t, y = f['t'], f['y']
+    orders = [int(x) for x in f['listDoG']]
+    seen = []
+
+    def runner(nP, p0, idx):
+        j = orders.index(nP)
+        np.testing.assert_array_equal(p0, f['trial_p0'][idx, j, :nP])        # same initial guess, bitwise
+        seen.append((nP, idx.copy()))
+        ok = f['trial_quality'][idx, j, 0]
+        K = nP // 2
+        popt = f['trial_popt'][idx, j, :nP].copy()
+        dP = f['trial_dP'][idx, j, :nP].copy()
+        # hand back values whose "dP > popt" flag equals the reference's flag 1 (the golden popt are sorted by tau,
+        # the comparison is permutation invariant within C / tau because errors are permuted alike)
+        status = np.where(ok, 2, 0).astype(np.int32)
+        popt[~ok] = 0.5
+        dP[~ok] = 0.0
+        return popt, dP, f['trial_chi'][idx, j], status
+
+    best, per_order = fitCt.order_search_batch(t, y, runner, orders, 0.5)
+    for i in range(y.shape[0]):
+        assert best[i] >= 0
+        assert orders[best[i]] == f['sel_nParams'][i]
+        assert per_order[best[i]]['chiSq'][i] == f['sel_chi'][i]
+        for j, res in enumerate(per_order):
+            if np.isfinite(res['p0'][i, 0]):
+                assert list(res['quality'][i]) == list(f['trial_quality'][i, j])
+    # residues stop individually: later orders are only solved for those still searching
+    assert all(len(ix) <= y.shape[0] for _, ix in seen)
+    assert len(seen[-1][1]) <= len(seen[0][1])
+
+
+def test_initial_guess_batch_equals_scalar():
+    f = golden('cfg2_fit.npz')
+    for nP in (2, 3, 4, 5, 7, 9):
+        p0b, C0b, S2b = fitCt.initial_guess_batch(f['t'], f['y'], nP)
+        for i in range(f['y'].shape[0]):
+            p0, C0, S2 = fitCt.initial_guess(f['t'][i], f['y'][i], nP)
+            np.testing.assert_array_equal(p0b[i], p0)
+            assert S2b[i] == S2
+
+
+def test_chunk_starts_match_reformat():
+    a = np.arange(7 * 2 * 3, dtype=np.float32).reshape(7, 2, 3)
+    b = 100 + np.arange(5 * 2 * 3, dtype=np.float32).reshape(5, 2, 3)
+    cat, starts, R = hostct.concat_with_chunk_starts([a, b], 3)
+    assert R == 3 and list(starts) == [0, 3, 7]
+    v4 = np.stack([cat[s:s + 3] for s in starts])
+    ref = np.concatenate([a[:6], b[:3]]).reshape(3, 3, 2, 3)
+    np.testing.assert_array_equal(v4, ref)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        np.testing.assert_array_equal(hostct.reformat_vecs_by_tau([a, b], 1.0, 3.0), ref)
+
+
+def test_shard_ranges_cover_everything():
+    for V in (1, 7, 512, 2048, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                v0, nV = srdist.shard_range(V, r, world)
+                cover += list(range(v0, v0 + nV))
+            assert cover == list(range(V))
+            sizes = srdist.shard_sizes(V, world)
+            assert max(sizes) - min(sizes) <= 1

@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', type=str, default='cfg3', choices=['cfg2', 'cfg3'])
     ap.add_argument('--vectors', type=int, default=None, help='vectors per GPU (default: the config value)')
+    ap.add_argument('--depth', type=int, default=3, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--stage-breakdown', action='store_true', help='after the timed loop, print a synchronised per-stage wall-time breakdown to stderr (diagnostic)')
     ap.add_argument('--cpu-sample-vectors', type=int, default=8)
@@ -124,42 +125,38 @@ def main():
 
     with torch.cuda.stream(stream):
         pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], q_rot=q, Diso=synth.DISO, aniso=aniso,
-                              field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA)
+                              field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA, depth=args.depth, stream=stream)
 
-        def gather_results():
+        def gather_results(slot):
             if world == 1:
                 return
-            for tns in (pipe.Ct, pipe.dCt, pipe.hist):
+            for tns in (slot.Ct, slot.dCt, slot.hist):
                 out = [torch.empty_like(tns) for _ in range(world)]
                 dist.all_gather(out, tns.contiguous())
-            r = torch.from_numpy(np.ascontiguousarray(pipe.relax_out)).to(dev)
+            r = torch.from_numpy(np.ascontiguousarray(slot.relax_out)).to(dev)
             out = [torch.empty_like(r) for _ in range(world)]
             dist.all_gather(out, r)
 
-        def one_step(ev=None):
-            pipe.stage_pack(vecs)
-            if ev is not None:
-                ev[0].record(stream)
-            pipe.stage_ct()
-            if ev is not None:
-                ev[1].record(stream)
-            pipe.stage_hist()
-            if ev is not None:
-                ev[2].record(stream)
-            pipe.stage_fit()
-            pipe.stage_relax()
-            gather_results()
+        def run_batches(nb, events=None):
+            """nb batches (steps) through the pipeline; batch k is finished depth-1 batches after it began"""
+            D = pipe.depth
+            for k in range(nb):
+                pipe.begin(vecs, k, None if events is None else events[k])
+                if k >= D - 1:
+                    pipe.finish(k - D + 1)
+                    gather_results(pipe.slots[(k - D + 1) % D])
+            for k in range(max(0, nb - D + 1), nb):
+                pipe.finish(k)
+                gather_results(pipe.slots[k % D])
 
-        for _ in range(args.warmup):
-            one_step()
+        run_batches(args.warmup)
         events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for k in range(args.steps):
-            one_step(events[k])
+        run_batches(args.steps, events)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -169,7 +166,13 @@ def main():
     if args.stage_breakdown and rank == 0:
         with torch.cuda.stream(stream):
             names = ['pack', 'ct', 'hist', 'fit', 'relax']
-            fns = [lambda: pipe.stage_pack(vecs), pipe.stage_ct, pipe.stage_hist, pipe.stage_fit, pipe.stage_relax]
+            s0 = pipe.slots[0]
+
+            def _fit():
+                pipe.stage_fit_begin(s0, defer_last=False)
+                pipe.stage_fit_end(s0)
+            fns = [lambda: pipe.stage_pack(vecs), lambda: pipe.stage_ct(s0), lambda: pipe.stage_hist(s0), _fit,
+                   lambda: pipe.stage_relax(s0)]
             acc = {n: 0.0 for n in names}
             for _ in range(3):
                 for n, fn in zip(names, fns):
@@ -203,7 +206,7 @@ def main():
             'config': {'workload': 'BASELINE cfg%d per GPU: %d frames x %d vectors, %d chunks x %d frames, %d lags, '
                                    '%s, fits 2/3/5/7/9 params, 1 field' % (cfg, s['frames'], V, s['R'], s['F'], s['L'],
                                                                            'axisymmetric D + q_ext + 72x36 histogram' if cfg == 3 else 'isotropic D'),
-                       'vectors_per_gpu': V, 'exact_triples_per_gpu': triples, 'sharding': 'vectors (no data-path collective; all-gather of results)'},
+                       'vectors_per_gpu': V, 'exact_triples_per_gpu': triples, 'sharding': 'vectors (no data-path collective; all-gather of results)', 'batches_in_flight': pipe.depth},
             'roofline': {'bound': 'valu-fp32 (non-MFMA vector FMA; FP32 MFMA peak is the same 157.3)', 'kernel': 'k_ct_palmer',
                          'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS,
                          'traffic': None, 'kernel_ms': ct_ms, 'flop_per_triple': 8,

@@ -115,9 +115,11 @@ int sr_expfit_lm_f64(sr_ctx *, const double *t, const double *C, const double *s
                      double *popt, double *pcov, double *chisq, int *status, int *n_iter);
 /* device-pointer form; skip (nRes bytes, device, may be NULL): residues with skip[i] != 0 are left
  * untouched (used by the host-side model-order search, which stops residues individually);
- * max_iter < 0 selects the analytic Jacobian instead of scipy's 2-point differences. */
+ * max_iter < 0 selects the analytic Jacobian instead of scipy's 2-point differences;
+ * work (device, nRes*2*L doubles, may be NULL = context-owned): residual scratch; pass one buffer per
+ * concurrently running launch when fits are enqueued on several streams. */
 int sr_expfit_lm_f64_dev(sr_ctx *, const double *t, const double *C, const double *sigma, int nRes, int L, int P,
-                         const double *p0, double tau_max, int max_iter, const unsigned char *skip,
+                         const double *p0, double tau_max, int max_iter, const unsigned char *skip, double *work,
                          double *popt, double *pcov, double *chisq, int *status, int *n_iter);
 
 /* ---- kernel 3a: J(omega) and R1/R2/NOE/rho ----------------------------------------------

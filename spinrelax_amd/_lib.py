@@ -49,7 +49,7 @@ SIGNATURES = {
     'sr_expfit_lm_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_double,
                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'sr_expfit_lm_f64_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_double,
-                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'sr_transpose_f64_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'sr_jomega_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     'sr_jomega_relax_f64': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -794,13 +794,13 @@ int dispatch_trf(sr_ctx *ctx, int P, const FitArgs &a)
 extern "C" {
 
 int sr_expfit_lm_f64_dev(sr_ctx *ctx, const double *t, const double *C, const double *sigma, int nRes, int L, int P,
-                         const double *p0, double tau_max, int max_iter, const unsigned char *skip, double *popt,
-                         double *pcov, double *chisq, int *status, int *n_iter)
+                         const double *p0, double tau_max, int max_iter, const unsigned char *skip, double *work,
+                         double *popt, double *pcov, double *chisq, int *status, int *n_iter)
 {
     SR_CHECK_CTX(ctx);
     SR_REQUIRE(t && C && p0 && popt && pcov && chisq && status && n_iter, -2, "sr_expfit_lm_f64_dev: null pointer");
     SR_REQUIRE(nRes >= 1 && L >= 1 && P >= 2 && P <= kNmax, -3, "sr_expfit_lm_f64_dev: bad sizes nRes=%d L=%d P=%d", nRes, L, P);
-    double *fws = (double *)sr_workspace(ctx, SR_WS_PSUM, (size_t)nRes * 2 * L * sizeof(double));
+    double *fws = work ? work : (double *)sr_workspace(ctx, SR_WS_FIT, (size_t)nRes * 2 * L * sizeof(double));
     if (!fws) return -5;
     FitArgs a;
     a.t = t; a.y = C; a.sigma = sigma; a.p0 = p0; a.skip = skip; a.tau_max = tau_max;
@@ -829,7 +829,7 @@ int sr_expfit_lm_f64(sr_ctx *ctx, const double *t, const double *C, const double
     if (sigma) SR_HIP(hipMemcpyAsync(s_d, sigma, nL * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     SR_HIP(hipMemcpyAsync(p0_d, p0, nP * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     double *popt_d = out, *pcov_d = out + nP, *chi_d = pcov_d + nP * P;
-    int rc = sr_expfit_lm_f64_dev(ctx, t_d, y_d, sigma ? s_d : nullptr, nRes, L, P, p0_d, tau_max, max_iter, nullptr, popt_d, pcov_d,
+    int rc = sr_expfit_lm_f64_dev(ctx, t_d, y_d, sigma ? s_d : nullptr, nRes, L, P, p0_d, tau_max, max_iter, nullptr, nullptr, popt_d, pcov_d,
                                   chi_d, iout, iout + nRes);
     if (rc) return rc;
     SR_HIP(hipMemcpyAsync(popt, popt_d, nP * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

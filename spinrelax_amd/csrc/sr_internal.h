@@ -7,7 +7,7 @@
 #include <cstring>
 #include "../../include/spinrelax_hip.h"
 
-#define SR_NSLOTS 12
+#define SR_NSLOTS 13
 
 struct sr_ctx {
     int device;
@@ -25,7 +25,8 @@ enum {
     SR_WS_PSUM,         // C(t) raw sums
     SR_WS_OUT0, SR_WS_OUT1, SR_WS_OUT2, SR_WS_OUT3,
     SR_WS_IN0, SR_WS_IN1, SR_WS_IN2, SR_WS_IN3,
-    SR_WS_MISC
+    SR_WS_MISC,
+    SR_WS_FIT           // residual work space of the fit kernel (when the caller passes none)
 };
 
 void sr_set_error(const char *fmt, ...);

@@ -391,31 +391,48 @@ def host_runner(t, y, dy, ctx=None):
     return run
 
 
-def fit_batch_arrays(t, y, nParams, runner, active=None):
-    """conduct_curve_fitting(bReInitialise=True) for a batch.  Returns a dict of arrays over ALL n residues
-    (rows of inactive residues are undefined): ok, chiSq, quality (n,3), popt, dP, p0."""
+def fit_request(t, y, nParams, active=None):
+    """First half of conduct_curve_fitting(bReInitialise=True) for a batch: the residues to solve and their
+    initial guesses.  Returns dict(nParams, idx, p0, C0, S2_0)."""
     n = y.shape[0]
-    K, free = split_nparams(nParams)
     idx = np.arange(n) if active is None else np.flatnonzero(active)
+    if idx.size == 0:
+        return dict(nParams=nParams, idx=idx, p0=np.empty((0, nParams)), C0=None, S2_0=None, n=n)
+    p0, C0, S2_0 = initial_guess_batch(t[idx], y[idx], nParams)
+    return dict(nParams=nParams, idx=idx, p0=p0, C0=C0, S2_0=S2_0, n=n)
+
+
+def fit_collect(req, popt, dP, chi, status):
+    """Second half: quality flags (fitting_Ct_functions.py:320-338; the sum>1 test runs on the initial guess --
+    reference quirk) and the per-residue arrays over ALL n residues (rows of inactive residues undefined)."""
+    nParams, idx, n = req['nParams'], req['idx'], req['n']
+    K, free = split_nparams(nParams)
     res = dict(nParams=nParams, ok=np.zeros(n, dtype=bool), chiSq=np.full(n, np.inf), quality=np.zeros((n, 3), dtype=bool),
                popt=np.full((n, nParams), np.nan), dP=np.full((n, nParams), np.nan), p0=np.full((n, nParams), np.nan))
     if idx.size == 0:
         return res
-    p0, C0, S2_0 = initial_guess_batch(t[idx], y[idx], nParams)
-    popt, dP, chi, status = runner(nParams, p0, idx)
     ok = status > 0
-    # quality flags, fitting_Ct_functions.py:320-338 (sum>1 test on the initial guess: reference quirk)
     with np.errstate(invalid='ignore'):
         q1 = ~np.any(dP > popt, axis=1)
+    C0, S2_0 = req['C0'], req['S2_0']
     S2chk = S2_0 if free else 1.0 - np.sum(C0, axis=1)
     q2 = ~(S2chk + np.sum(C0, axis=1) > 1.0)
-    res['p0'][idx] = p0
+    res['p0'][idx] = req['p0']
     res['ok'][idx] = ok
     res['chiSq'][idx] = np.where(ok, chi, np.inf)
     res['quality'][idx] = np.stack([ok, np.where(ok, q1, True), np.where(ok, q2, True)], axis=1)
     res['popt'][idx] = popt
     res['dP'][idx] = dP
     return res
+
+
+def fit_batch_arrays(t, y, nParams, runner, active=None):
+    """conduct_curve_fitting(bReInitialise=True) for a batch through a synchronous runner."""
+    req = fit_request(t, y, nParams, active)
+    if req['idx'].size == 0:
+        return fit_collect(req, None, None, None, None)
+    popt, dP, chi, status = runner(nParams, req['p0'], req['idx'])
+    return fit_collect(req, popt, dP, chi, status)
 
 
 def _fit_dict(res, i):
@@ -443,36 +460,94 @@ def fit_batch(t, y, dy, nParams, active=None, ctx=None):
     return out
 
 
-def order_search_batch(t, y, runner, listDoG=(2, 3, 5, 7, 9), chiSqThreshold=0.5):
-    """optimised_curve_fitting (fitting_Ct_functions.py:278-304) for all residues in lock-step, vectorised:
-    each model order is one batched solve over the residues still searching.  Returns
-    (best_order_index (n,) with -1 = never satisfied, list of per-order batch results)."""
-    n = y.shape[0]
-    first = np.ones(n, dtype=bool)
-    done = np.zeros(n, dtype=bool)
-    best = np.full(n, -1, dtype=int)
-    best_chi = np.full(n, np.inf)
-    per_order = []
-    for j, nP in enumerate(listDoG):
-        active = ~done
+class OrderSearchBatch:
+    """optimised_curve_fitting (fitting_Ct_functions.py:278-304) for all residues in lock-step, as a resumable
+    state machine: `request()` hands out the next model order to solve (residues still searching + their
+    initial guesses), `submit()` takes the solver's answer and applies the reference's accept / reject rules.
+    Splitting the two lets a caller run the solve asynchronously (spinrelax_amd/pipeline.py overlaps the
+    long tail of the last order with the next batch's C(t) kernel)."""
+
+    def __init__(self, t, y, listDoG=(2, 3, 5, 7, 9), chiSqThreshold=0.5):
+        self.t, self.y = t, y
+        self.orders = tuple(listDoG)
+        self.thr = chiSqThreshold
+        n = y.shape[0]
+        self.first = np.ones(n, dtype=bool)
+        self.done = np.zeros(n, dtype=bool)
+        self.best = np.full(n, -1, dtype=int)
+        self.best_chi = np.full(n, np.inf)
+        self.per_order = []
+        self.j = 0
+        self._req = None
+
+    def request(self):
+        """Next (order index, request dict) or None when the search is over."""
+        if self.j >= len(self.orders):
+            return None
+        active = ~self.done
         if not active.any():
-            break
-        res = fit_batch_arrays(t, y, nP, runner, active)
-        per_order.append(res)
+            return None
+        self._active = active
+        self._req = fit_request(self.t, self.y, self.orders[self.j], active)
+        return self._req
+
+    def submit(self, popt, dP, chi, status):
+        res = fit_collect(self._req, popt, dP, chi, status)
+        j, active = self.j, self._active
+        self.per_order.append(res)
         allq = res['quality'].all(axis=1)
-        chi = res['chiSq']
-        was_first = first.copy()
+        chi_all = res['chiSq']
+        was_first = self.first.copy()
         take_first = active & was_first & allq
-        best[take_first] = j
-        best_chi[take_first] = chi[take_first]
-        first[take_first] = False
+        self.best[take_first] = j
+        self.best_chi[take_first] = chi_all[take_first]
+        self.first[take_first] = False
         later = active & ~was_first
-        stop = later & (~allq | (chi >= best_chi * chiSqThreshold))
-        done |= stop
+        stop = later & (~allq | (chi_all >= self.best_chi * self.thr))
+        self.done |= stop
         acc = later & ~stop
-        best[acc] = j
-        best_chi[acc] = chi[acc]
-    return best, per_order
+        self.best[acc] = j
+        self.best_chi[acc] = chi_all[acc]
+        self.j += 1
+        return res
+
+    def selected_arrays(self, Kmax=None):
+        """S2 (n,), C (n,Kmax), tau (n,Kmax) sorted by tau, nComps (n,), chiSq (n,) of the selected models
+        (vectorised; residues without a satisfactory fit have nComps = 0 and chiSq = nan)."""
+        n = self.y.shape[0]
+        Kmax = max(self.orders) // 2 if Kmax is None else Kmax
+        S2 = np.zeros(n)
+        C = np.zeros((n, Kmax))
+        tau = np.ones((n, Kmax))
+        K = np.zeros(n, dtype=np.int32)
+        chi = np.full(n, np.nan)
+        for j, res in enumerate(self.per_order):
+            sel = np.flatnonzero(self.best == j)
+            if sel.size == 0:
+                continue
+            k, free = split_nparams(res['nParams'])
+            popt = res['popt'][sel]
+            Cj, tj = popt[:, :k], popt[:, k:2 * k]
+            order = np.argsort(tj, axis=1)
+            C[sel, :k] = np.take_along_axis(Cj, order, axis=1)
+            tau[sel, :k] = np.take_along_axis(tj, order, axis=1)
+            S2[sel] = popt[:, -1] if free else 1.0 - np.sum(Cj, axis=1)
+            K[sel] = k
+            chi[sel] = res['chiSq'][sel]
+        return S2, C, tau, K, chi
+
+
+def order_search_batch(t, y, runner, listDoG=(2, 3, 5, 7, 9), chiSqThreshold=0.5):
+    """Synchronous driver of OrderSearchBatch.  Returns (best_order_index (n,) with -1 = never satisfied, list of
+    per-order batch results)."""
+    search = OrderSearchBatch(t, y, listDoG, chiSqThreshold)
+    while True:
+        req = search.request()
+        if req is None:
+            break
+        popt, dP, chi, status = runner(req['nParams'], req['p0'], req['idx'])
+        search.submit(popt, dP, chi, status)
+    return search.best, search.per_order
 
 
 def optimised_curve_fitting_batch(names, t, y, dy, listDoG=(2, 3, 5, 7, 9), chiSqThreshold=0.5, fp=sys.stdout, ctx=None,

@@ -179,9 +179,9 @@ class Context:
         return popt, pcov, chisq, status, nfev
 
     def expfit_dev(self, t_ptr, y_ptr, sigma_ptr, nRes, L, P, p0_ptr, tau_max, max_nfev, popt_ptr, pcov_ptr, chisq_ptr,
-                   status_ptr, nfev_ptr, skip_ptr=None):
+                   status_ptr, nfev_ptr, skip_ptr=None, work_ptr=None):
         check(self.lib.sr_expfit_lm_f64_dev(self.h, t_ptr, y_ptr, sigma_ptr, nRes, L, P, p0_ptr, float(tau_max),
-                                            int(max_nfev), skip_ptr, popt_ptr, pcov_ptr, chisq_ptr, status_ptr, nfev_ptr),
+                                            int(max_nfev), skip_ptr, work_ptr, popt_ptr, pcov_ptr, chisq_ptr, status_ptr, nfev_ptr),
               'sr_expfit_lm_f64_dev')
 
     def transpose_dev(self, in_ptr, rows, cols, out_ptr):

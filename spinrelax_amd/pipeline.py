@@ -10,8 +10,16 @@ Device-resident single-process pipeline over one shard of vectors:
       -> kernel 3a J(omega), R1/R2/NOE/rho with the histogram as weights  (calculate-relaxations-from-Ct.py:125-191)
 
 This is what run-all.bash's Step 3 + Step 4 compute (run-all.bash:476-533) without the text files in
-between; bench.py times it and the CLI scripts reuse its stages one at a time.  torch is used for device
-memory and streams only; every computation goes through the C ABI.
+between; bench.py times it.  torch is used for device memory, streams and events only; every computation
+goes through the C ABI.
+
+Batches and overlap.  A GPU works through its vectors in batches (512 vectors in the benchmark).  The
+fits are a latency chain: the last model order (9 parameters) runs on the few residues that got that far
+and its wall time is set by ONE straggler (818 of the 900 allowed evaluations in the benchmark data,
+median 32), on one CU, while the rest of the chip idles.  `begin(batch)` therefore enqueues that last
+order on a side stream and returns; `finish(batch)` (called `depth - 1` batches later) collects it, applies
+the accept/reject rule and runs the relaxation kernel.  All per-batch device buffers exist `depth` times.
+`depth = 1` is the plain serial pipeline (`step()`).
 """
 import numpy as np
 import torch
@@ -22,9 +30,34 @@ from . import _hostmath as hm
 from . import spectral_densities as sd
 
 
+class _Slot:
+    """Device buffers of one in-flight batch."""
+
+    def __init__(self, dev, V, L, R, nbins, Pmax):
+        f64 = dict(device=dev, dtype=torch.float64)
+        self.Ct = torch.empty((L, V), **f64)
+        self.dCt = torch.empty((L, V), **f64)
+        self.CtT = torch.empty((V, L), **f64)
+        self.dCtT = torch.empty((V, L), **f64)
+        self.hist = torch.empty((V, nbins), **f64)
+        self.vecsum = torch.empty((V, 3), **f64)
+        self.outer = torch.empty((R, V, 6), **f64)
+        self.p0 = torch.empty((V, Pmax), **f64)
+        self.popt = torch.empty((V, Pmax), **f64)
+        self.pcov = torch.empty((V, Pmax * Pmax), **f64)
+        self.chi = torch.empty((V,), **f64)
+        self.status = torch.empty((V,), device=dev, dtype=torch.int32)
+        self.nfev = torch.empty((V,), device=dev, dtype=torch.int32)
+        self.skip = torch.zeros((V,), device=dev, dtype=torch.uint8)
+        self.fitwork = torch.empty((V, 2, L), **f64)
+        self.search = None
+        self.pending = None          # (request, event) of the asynchronous last order
+        self.relax_out = None
+
+
 class DevicePipeline:
     def __init__(self, ctx, device, frames, V, R, F, dt, q_rot=None, Diso=None, aniso=None, field_MHz=(600.133,),
-                 zeta=0.890023, histBinX=72, listDoG=(2, 3, 5, 7, 9), csa=None):
+                 zeta=0.890023, histBinX=72, listDoG=(2, 3, 5, 7, 9), csa=None, depth=1, stream=None):
         self.ctx = ctx
         self.dev = device
         self.frames, self.V, self.R, self.F, self.dt = frames, V, R, F, dt
@@ -38,133 +71,176 @@ class DevicePipeline:
         self.listDoG = tuple(listDoG)
         self.edges = hostct.lambert_edges(histBinX)
         self.nbins = histBinX * int(histBinX / 2)
-        f64 = dict(device=device, dtype=torch.float64)
+        self.depth = max(1, int(depth))
+        self.main = stream if stream is not None else torch.cuda.current_stream(device)
+        # one side stream per slot so that the stragglers of consecutive batches overlap each other as well
+        self.sides = [torch.cuda.Stream(device=device) for _ in range(self.depth)] if self.depth > 1 else None
         self.soa = torch.empty((V, 3, self.Npad), device=device, dtype=torch.float32)
-        self.Ct = torch.empty((self.L, V), **f64)
-        self.dCt = torch.empty((self.L, V), **f64)
-        self.CtT = torch.empty((V, self.L), **f64)
-        self.dCtT = torch.empty((V, self.L), **f64)
-        self.hist = torch.empty((V, self.nbins), **f64)
-        self.vecsum = torch.empty((V, 3), **f64)
-        self.outer = torch.empty((R, V, 6), **f64)
+        Pmax = max(self.listDoG)
+        self.slots = [_Slot(device, V, self.L, R, self.nbins, Pmax) for _ in range(self.depth)]
         t = hostct.calculate_dt(dt, F * dt)
         self.t_host = np.ascontiguousarray(np.broadcast_to(t, (V, self.L)))
         self.t_dev = torch.from_numpy(self.t_host).to(device)
-        Pmax = max(self.listDoG)
-        self.p0_dev = torch.empty((V, Pmax), **f64)
-        self.popt_dev = torch.empty((V, Pmax), **f64)
-        self.pcov_dev = torch.empty((V, Pmax * Pmax), **f64)
-        self.chi_dev = torch.empty((V,), **f64)
-        self.status_dev = torch.empty((V,), device=device, dtype=torch.int32)
-        self.nfev_dev = torch.empty((V,), device=device, dtype=torch.int32)
-        self.skip_dev = torch.zeros((V,), device=device, dtype=torch.uint8)
+        self.tau_max = self.t_host[0, -1] * 10                     # fitting_Ct_functions.py:324
         self.binvecs = hm.lambert_bin_vectors(self.edges)
         self.csa = csa
         self.nfev_total = 0
         self.nfev_last = {}
-
-    # ---- stages ----
-    def stage_pack(self, vecs):
-        self.ctx.pack_soa_dev(vecs.data_ptr(), self.frames, vecs.shape[1], 0, self.V, self.soa.data_ptr(), self.Npad)
-
-    def stage_ct(self):
-        self.ctx.ct_palmer_dev(self.soa.data_ptr(), self.Npad, self.R, self.F, self.V, self.Ct.data_ptr(), self.dCt.data_ptr())
-
-    def stage_hist(self):
-        self.ctx.rotate_hist_dev(self.soa.data_ptr(), self.Npad, self.N, self.V, self.q, self.edges[0], self.edges[1],
-                                 self.hist.data_ptr(), self.vecsum.data_ptr(), self.outer.data_ptr(), self.F)
-
-    def _runner(self, tau_max):
-        V = self.V
-
-        def run(nParams, p0, idx):
-            # residues not in idx are skipped on the device; their rows keep stale values that are never read
-            skip = np.ones(V, dtype=np.uint8)
-            skip[idx] = 0
-            p0_full = np.zeros((V, nParams))
-            p0_full[idx] = p0
-            self.skip_dev.copy_(torch.from_numpy(skip))
-            p0v = self.p0_dev.view(-1)[: V * nParams].view(V, nParams)
-            p0v.copy_(torch.from_numpy(p0_full))
-            self.ctx.expfit_dev(self.t_dev.data_ptr(), self.CtT.data_ptr(), self.dCtT.data_ptr(), V, self.L, nParams,
-                                p0v.data_ptr(), tau_max, 100 * nParams, self.popt_dev.data_ptr(), self.pcov_dev.data_ptr(),
-                                self.chi_dev.data_ptr(), self.status_dev.data_ptr(), self.nfev_dev.data_ptr(),
-                                skip_ptr=self.skip_dev.data_ptr())
-            popt = self.popt_dev.view(-1)[: V * nParams].view(V, nParams).cpu().numpy()[idx]
-            pcov = self.pcov_dev.view(-1)[: V * nParams * nParams].view(V, nParams, nParams)
-            dvar = torch.diagonal(pcov, dim1=1, dim2=2).cpu().numpy()[idx]
-            chi = self.chi_dev.cpu().numpy()[idx]
-            status = self.status_dev.cpu().numpy()[idx]
-            nf = self.nfev_dev.cpu().numpy()[idx]
-            self.nfev_total += int(nf.sum())
-            self.nfev_last[nParams] = nf
-            with np.errstate(invalid='ignore'):
-                dP = np.sqrt(dvar)
-            return popt, dP, chi, status
-        return run
-
-    def stage_fit(self):
-        self.ctx.transpose_dev(self.Ct.data_ptr(), self.L, self.V, self.CtT.data_ptr())
-        self.ctx.transpose_dev(self.dCt.data_ptr(), self.L, self.V, self.dCtT.data_ptr())
-        # the initial guesses only need the first / last ten lags of every residue (fitting_Ct_functions.py:366-368)
-        head = self.CtT[:, :10].cpu().numpy()
-        tail = self.CtT[:, -10:].cpu().numpy()
-        y_small = _EdgeOnly(head, tail, self.L)
-        best, per_order = fitCt.order_search_batch(self.t_host, y_small, self._runner(self.t_host[0, -1] * 10), self.listDoG)
-        self.fit_best, self.fit_orders = best, per_order
-        return best, per_order
-
-    def selected_params(self):
-        """S2, C (V,Kmax), tau (V,Kmax), nComps of the selected models (components sorted by tau)."""
-        V = self.V
-        Kmax = max(self.listDoG) // 2
-        S2 = np.zeros(V)
-        C = np.zeros((V, Kmax))
-        tau = np.ones((V, Kmax))
-        K = np.zeros(V, dtype=np.int32)
-        chi = np.full(V, np.nan)
-        for i in range(V):
-            if self.fit_best[i] < 0:
-                continue
-            f = fitCt._fit_dict(self.fit_orders[self.fit_best[i]], i)
-            k = len(f['C'])
-            K[i] = k
-            C[i, :k] = f['C']
-            tau[i, :k] = f['tau']
-            S2[i] = f['S2']
-            chi[i] = f['chiSq']
-        return S2, C, tau, K, chi
-
-    def stage_relax(self):
-        S2, C, tau, K, _ = self.selected_params()
-        z = self.zeta
-        outs = []
+        # field-dependent constants of the old API (spectral_densities.py:1630-1645, 1696-1701), once
         oms, fdd, fcsa, tf, gr = [], [], [], [], []
         for MHz in self.fields:
             RObj = sd.relaxationModel('NH', 2.0 * np.pi * (MHz * 1e6) / 267.513e6)
             RObj.set_time_unit('ps')
             oms.append(RObj.omega)
             fdd.append(RObj.get_f_DD())
-            csa = np.repeat(RObj.gX.csa, self.V) if self.csa is None else np.asarray(self.csa, dtype=float)
-            fcsa.append(RObj.get_f_CSA(csa))
+            c = np.repeat(RObj.gX.csa, V) if csa is None else np.asarray(csa, dtype=float)
+            fcsa.append(RObj.get_f_CSA(c))
             tf.append(RObj.time_fact)
             gr.append(RObj.gH.gamma / RObj.gX.gamma)
+        self._relax_consts = (np.array(oms), np.array(fdd), np.array(fcsa), np.array(tf), np.array(gr))
+
+    # ---- stages on the main stream ----
+    def stage_pack(self, vecs):
+        self.ctx.pack_soa_dev(vecs.data_ptr(), self.frames, vecs.shape[1], 0, self.V, self.soa.data_ptr(), self.Npad)
+
+    def stage_ct(self, s=None):
+        s = s or self.slots[0]
+        self.ctx.ct_palmer_dev(self.soa.data_ptr(), self.Npad, self.R, self.F, self.V, s.Ct.data_ptr(), s.dCt.data_ptr())
+
+    def stage_hist(self, s=None):
+        s = s or self.slots[0]
+        self.ctx.rotate_hist_dev(self.soa.data_ptr(), self.Npad, self.N, self.V, self.q, self.edges[0], self.edges[1],
+                                 s.hist.data_ptr(), s.vecsum.data_ptr(), s.outer.data_ptr(), self.F)
+
+    # ---- fits ----
+    def _launch_fit(self, s, req):
+        V, nP = self.V, req['nParams']
+        skip = np.ones(V, dtype=np.uint8)
+        skip[req['idx']] = 0
+        p0_full = np.zeros((V, nP))
+        p0_full[req['idx']] = req['p0']
+        s.skip.copy_(torch.from_numpy(skip))
+        p0v = s.p0.view(-1)[: V * nP].view(V, nP)
+        p0v.copy_(torch.from_numpy(p0_full))
+        self.ctx.expfit_dev(self.t_dev.data_ptr(), s.CtT.data_ptr(), s.dCtT.data_ptr(), V, self.L, nP, p0v.data_ptr(),
+                            self.tau_max, 100 * nP, s.popt.data_ptr(), s.pcov.data_ptr(), s.chi.data_ptr(),
+                            s.status.data_ptr(), s.nfev.data_ptr(), skip_ptr=s.skip.data_ptr(), work_ptr=s.fitwork.data_ptr())
+
+    def _collect_fit(self, s, req):
+        V, nP, idx = self.V, req['nParams'], req['idx']
+        popt = s.popt.view(-1)[: V * nP].view(V, nP).cpu().numpy()[idx]
+        pcov = s.pcov.view(-1)[: V * nP * nP].view(V, nP, nP)
+        dvar = torch.diagonal(pcov, dim1=1, dim2=2).cpu().numpy()[idx]
+        chi = s.chi.cpu().numpy()[idx]
+        status = s.status.cpu().numpy()[idx]
+        nf = s.nfev.cpu().numpy()[idx]
+        self.nfev_total += int(nf.sum())
+        self.nfev_last[nP] = nf
+        with np.errstate(invalid='ignore'):
+            dP = np.sqrt(dvar)
+        s.search.submit(popt, dP, chi, status)
+
+    def stage_fit_begin(self, s, defer_last):
+        self.ctx.transpose_dev(s.Ct.data_ptr(), self.L, self.V, s.CtT.data_ptr())
+        self.ctx.transpose_dev(s.dCt.data_ptr(), self.L, self.V, s.dCtT.data_ptr())
+        # the initial guesses only need the first / last ten lags of every residue (fitting_Ct_functions.py:366-368)
+        head = s.CtT[:, :10].cpu().numpy()
+        tail = s.CtT[:, -10:].cpu().numpy()
+        s.search = fitCt.OrderSearchBatch(self.t_host, _EdgeOnly(head, tail, self.L), self.listDoG)
+        s.pending = None
+        while True:
+            req = s.search.request()
+            if req is None:
+                break
+            last = (s.search.j == len(self.listDoG) - 1)
+            if last and defer_last:
+                # enqueue behind everything already on the main stream, on the side stream; collect later
+                side = self.sides[self.slots.index(s)]
+                ready = torch.cuda.Event()
+                ready.record(self.main)
+                side.wait_event(ready)
+                self.ctx.set_stream(side.cuda_stream)
+                with torch.cuda.stream(side):
+                    self._launch_fit(s, req)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                self.ctx.set_stream(self.main.cuda_stream)
+                s.pending = (req, done)
+                break
+            self._launch_fit(s, req)
+            self._collect_fit(s, req)
+
+    def stage_fit_end(self, s):
+        if s.pending is not None:
+            req, done = s.pending
+            done.synchronize()
+            self._collect_fit(s, req)
+            s.pending = None
+        self.fit_best, self.fit_orders = s.search.best, s.search.per_order
+
+    def selected_params(self, s=None):
+        s = s or self.slots[0]
+        return s.search.selected_arrays(Kmax=max(self.listDoG) // 2)
+
+    def stage_relax(self, s=None):
+        s = s or self.slots[0]
+        S2, C, tau, K, _ = self.selected_params(s)
+        z = self.zeta
+        oms, fdd, fcsa, tf, gr = self._relax_consts
         if self.aniso is None or self.aniso == 1.0:
-            out, _ = self.ctx.relax(1, [self.Diso], np.array(oms), fdd, np.array(fcsa), tf, gr, z * S2, z * C, tau, K)
+            out, _ = self.ctx.relax(1, [self.Diso], oms, fdd, fcsa, tf, gr, z * S2, z * C, tau, K)
         else:
             Dpar, Dperp = hm.symmtop_from_iso(self.Diso, self.aniso)
-            out, _ = self.ctx.relax(2, [Dpar, Dperp], np.array(oms), fdd, np.array(fcsa), tf, gr, z * S2, z * C, tau, K,
-                                    binvecs=self.binvecs, weights_dev_ptr=self.hist.data_ptr(), noe_mode=0)
+            out, _ = self.ctx.relax(2, [Dpar, Dperp], oms, fdd, fcsa, tf, gr, z * S2, z * C, tau, K,
+                                    binvecs=self.binvecs, weights_dev_ptr=s.hist.data_ptr(), noe_mode=0)
+        s.relax_out = out
         self.relax_out = out
         return out
 
-    def step(self, vecs, with_hist=True):
+    # ---- batch-level API ----
+    def begin(self, vecs, k, events=None):
+        """Everything of batch k except the (deferred) last model order and the relaxation kernel."""
+        s = self.slots[k % self.depth]
         self.stage_pack(vecs)
-        self.stage_ct()
+        if events is not None:
+            events[0].record(self.main)
+        self.stage_ct(s)
+        if events is not None:
+            events[1].record(self.main)
+        self.stage_hist(s)
+        if events is not None:
+            events[2].record(self.main)
+        self.stage_fit_begin(s, defer_last=self.depth > 1)
+        return s
+
+    def finish(self, k):
+        s = self.slots[k % self.depth]
+        self.stage_fit_end(s)
+        return self.stage_relax(s)
+
+    def step(self, vecs, with_hist=True):
+        """Serial form (depth-independent): one batch from vectors to R1/R2/NOE."""
+        s = self.slots[0]
+        self.stage_pack(vecs)
+        self.stage_ct(s)
         if with_hist:
-            self.stage_hist()
-        self.stage_fit()
-        return self.stage_relax()
+            self.stage_hist(s)
+        self.stage_fit_begin(s, defer_last=False)
+        self.stage_fit_end(s)
+        return self.stage_relax(s)
+
+    # convenience views of slot 0 (serial use)
+    @property
+    def Ct(self):
+        return self.slots[0].Ct
+
+    @property
+    def dCt(self):
+        return self.slots[0].dCt
+
+    @property
+    def hist(self):
+        return self.slots[0].hist
 
 
 class _EdgeOnly:

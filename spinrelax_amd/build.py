@@ -12,6 +12,9 @@ LIB = os.path.join(HERE, 'libspinrelax_hip.so')
 SOURCES = ['sr_core.hip', 'sr_ct.hip', 'sr_vechist.hip', 'sr_fit.hip', 'sr_relax.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
+# sr_ct.hip: the SLP vectoriser packs the FMAs of the C(t) inner loop into v_pk_fma_f32, whose operand pairs then
+# need ~1 v_mov per FMA (rocprofv3: 4.8e9 VALU instructions for 2.5e9 FMAs); plain v_fma_f32 issues at the same rate.
+EXTRA = {'sr_ct.hip': ['-fno-slp-vectorize']}
 
 
 def _stale(target, deps):
@@ -30,7 +33,7 @@ def build(force=False, verbose=True):
             raise FileNotFoundError(s)
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ['-c', s, '-o', o]
+            cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)

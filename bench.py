@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', type=str, default='cfg3', choices=['cfg2', 'cfg3'])
     ap.add_argument('--vectors', type=int, default=None, help='vectors per GPU (default: the config value)')
-    ap.add_argument('--depth', type=int, default=3, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
+    ap.add_argument('--depth', type=int, default=4, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--stage-breakdown', action='store_true', help='after the timed loop, print a synchronised per-stage wall-time breakdown to stderr (diagnostic)')
     ap.add_argument('--cpu-sample-vectors', type=int, default=8)
@@ -138,16 +138,8 @@ def main():
             dist.all_gather(out, r)
 
         def run_batches(nb, events=None):
-            """nb batches (steps) through the pipeline; batch k is finished depth-1 batches after it began"""
-            D = pipe.depth
-            for k in range(nb):
-                pipe.begin(vecs, k, None if events is None else events[k])
-                if k >= D - 1:
-                    pipe.finish(k - D + 1)
-                    gather_results(pipe.slots[(k - D + 1) % D])
-            for k in range(max(0, nb - D + 1), nb):
-                pipe.finish(k)
-                gather_results(pipe.slots[k % D])
+            pipe.run(vecs, nb, events, on_finished=gather_results)
+            torch.cuda.synchronize()
 
         run_batches(args.warmup)
         events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]

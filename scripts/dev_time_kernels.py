@@ -13,18 +13,23 @@ from spinrelax_amd.hip import Context                # noqa: E402
 
 
 def main():
+    real = os.environ.get('SR_REAL_DATA')
     cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     nvec = int(sys.argv[2]) if len(sys.argv) > 2 else None
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     s = synth.config_shapes(cfg)
     V = nvec or s['V']
+    t0 = time.time()
+    pre = synth.synth_vectors_parallel(s['frames'], V, s['seed']) if real else None
     ctx = Context(0)
     print(ctx.device_info(), flush=True)
-    t0 = time.time()
     # cheap stand-in data for timing (real data only changes DVFS a little): random unit vectors per frame
-    g = torch.Generator(device='cuda').manual_seed(1)
-    vecs = torch.randn((s['frames'], V, 3), device='cuda', generator=g, dtype=torch.float32)
-    vecs = vecs / vecs.norm(dim=-1, keepdim=True)
+    if real:
+        vecs = torch.from_numpy(pre).cuda()
+    else:
+        g = torch.Generator(device='cuda').manual_seed(1)
+        vecs = torch.randn((s['frames'], V, 3), device='cuda', generator=g, dtype=torch.float32)
+        vecs = vecs / vecs.norm(dim=-1, keepdim=True)
     N = s['N']
     Npad = (s['frames'] + 63) // 64 * 64
     soa = torch.empty((V, 3, Npad), device='cuda', dtype=torch.float32)

@@ -20,6 +20,15 @@ median 32), on one CU, while the rest of the chip idles.  `begin(batch)` therefo
 order on a side stream and returns; `finish(batch)` (called `depth - 1` batches later) collects it, applies
 the accept/reject rule and runs the relaxation kernel.  All per-batch device buffers exist `depth` times.
 `depth = 1` is the plain serial pipeline (`step()`).
+
+Software pipeline (`run()`), three stages per batch on three kinds of streams:
+    front(k)  main stream : pack, C(t), histogram, transposes              (throughput-bound, fills the chip)
+    fits(k)   fit stream  : model orders 2..7 with the host in the loop    (latency-bound, few CUs)
+              side stream : last order, asynchronous
+    finish(k) fit stream  : collect the last order, select, relaxation kernel
+In iteration k the host enqueues front(k+1) first, then drives fits(k) while the C(t) kernel of batch k+1 keeps
+the chip (and its clock: an MI355X that idles for 5 ms runs the next C(t) launch ~17 % slower) busy, then
+finishes batch k-(depth-2).
 """
 import numpy as np
 import torch
@@ -51,6 +60,7 @@ class _Slot:
         self.skip = torch.zeros((V,), device=dev, dtype=torch.uint8)
         self.fitwork = torch.empty((V, 2, L), **f64)
         self.search = None
+        self.front_done = None
         self.pending = None          # (request, event) of the asynchronous last order
         self.relax_out = None
 
@@ -74,7 +84,10 @@ class DevicePipeline:
         self.depth = max(1, int(depth))
         self.main = stream if stream is not None else torch.cuda.current_stream(device)
         # one side stream per slot so that the stragglers of consecutive batches overlap each other as well
-        self.sides = [torch.cuda.Stream(device=device) for _ in range(self.depth)] if self.depth > 1 else None
+        # the fit kernels are short and latency-critical (the host waits on them): high-priority queues, so that their
+        # few workgroups are placed ahead of the thousands of queued C(t) workgroups of the next batch
+        self.sides = [torch.cuda.Stream(device=device, priority=-1) for _ in range(self.depth)] if self.depth > 2 else None
+        self.fitstream = torch.cuda.Stream(device=device, priority=-1) if self.depth > 1 else self.main
         self.soa = torch.empty((V, 3, self.Npad), device=device, dtype=torch.float32)
         Pmax = max(self.listDoG)
         self.slots = [_Slot(device, V, self.L, R, self.nbins, Pmax) for _ in range(self.depth)]
@@ -140,9 +153,10 @@ class DevicePipeline:
             dP = np.sqrt(dvar)
         s.search.submit(popt, dP, chi, status)
 
-    def stage_fit_begin(self, s, defer_last):
-        self.ctx.transpose_dev(s.Ct.data_ptr(), self.L, self.V, s.CtT.data_ptr())
-        self.ctx.transpose_dev(s.dCt.data_ptr(), self.L, self.V, s.dCtT.data_ptr())
+    def stage_fit_begin(self, s, defer_last, transposed=False):
+        if not transposed:
+            self.ctx.transpose_dev(s.Ct.data_ptr(), self.L, self.V, s.CtT.data_ptr())
+            self.ctx.transpose_dev(s.dCt.data_ptr(), self.L, self.V, s.dCtT.data_ptr())
         # the initial guesses only need the first / last ten lags of every residue (fitting_Ct_functions.py:366-368)
         head = s.CtT[:, :10].cpu().numpy()
         tail = s.CtT[:, -10:].cpu().numpy()
@@ -156,15 +170,16 @@ class DevicePipeline:
             if last and defer_last:
                 # enqueue behind everything already on the main stream, on the side stream; collect later
                 side = self.sides[self.slots.index(s)]
+                cur = torch.cuda.current_stream(self.dev)
                 ready = torch.cuda.Event()
-                ready.record(self.main)
+                ready.record(cur)
                 side.wait_event(ready)
                 self.ctx.set_stream(side.cuda_stream)
                 with torch.cuda.stream(side):
                     self._launch_fit(s, req)
                     done = torch.cuda.Event()
                     done.record(side)
-                self.ctx.set_stream(self.main.cuda_stream)
+                self.ctx.set_stream(cur.cuda_stream)
                 s.pending = (req, done)
                 break
             self._launch_fit(s, req)
@@ -198,29 +213,71 @@ class DevicePipeline:
         return out
 
     # ---- batch-level API ----
-    def begin(self, vecs, k, events=None):
-        """Everything of batch k except the (deferred) last model order and the relaxation kernel."""
+    def front(self, vecs, k, events=None):
+        """Stage 1 of batch k on the main stream: pack, C(t), histogram (+ the transposes the fits read)."""
         s = self.slots[k % self.depth]
-        self.stage_pack(vecs)
-        if events is not None:
-            events[0].record(self.main)
-        self.stage_ct(s)
-        if events is not None:
-            events[1].record(self.main)
-        self.stage_hist(s)
-        if events is not None:
-            events[2].record(self.main)
-        self.stage_fit_begin(s, defer_last=self.depth > 1)
+        self.ctx.set_stream(self.main.cuda_stream)
+        with torch.cuda.stream(self.main):
+            self.stage_pack(vecs)
+            if events is not None:
+                events[0].record(self.main)
+            self.stage_ct(s)
+            if events is not None:
+                events[1].record(self.main)
+            self.stage_hist(s)
+            if events is not None:
+                events[2].record(self.main)
+            self.ctx.transpose_dev(s.Ct.data_ptr(), self.L, self.V, s.CtT.data_ptr())
+            self.ctx.transpose_dev(s.dCt.data_ptr(), self.L, self.V, s.dCtT.data_ptr())
+            s.front_done = torch.cuda.Event()
+            s.front_done.record(self.main)
+        return s
+
+    def fits(self, k):
+        """Stage 2 of batch k on the fit stream (host in the loop); the last order goes to a side stream when
+        depth > 2.  (Solving all orders for all residues speculatively, without the host in the loop, was tried:
+        it gives the same selection but its 512 nine-parameter workgroups at 256 VGPRs displace two C(t)
+        workgroups each and cost more than the latency chain they remove.)"""
+        s = self.slots[k % self.depth]
+        self.fitstream.wait_event(s.front_done)
+        self.ctx.set_stream(self.fitstream.cuda_stream)
+        with torch.cuda.stream(self.fitstream):
+            self.stage_fit_begin(s, defer_last=self.depth > 2, transposed=True)
         return s
 
     def finish(self, k):
         s = self.slots[k % self.depth]
-        self.stage_fit_end(s)
-        return self.stage_relax(s)
+        self.ctx.set_stream(self.fitstream.cuda_stream)
+        with torch.cuda.stream(self.fitstream):
+            self.stage_fit_end(s)
+            out = self.stage_relax(s)
+        return out
+
+    def run(self, vecs, nb, events=None, on_finished=None):
+        """nb batches through the software pipeline.  on_finished(slot) is called for every finished batch."""
+        D = self.depth
+        lag = max(0, D - 2)
+        self.front(vecs, 0, None if events is None else events[0])
+        for k in range(nb):
+            if D > 1 and k + 1 < nb:
+                self.front(vecs, k + 1, None if events is None else events[k + 1])
+            self.fits(k)
+            if k - lag >= 0:
+                self.finish(k - lag)
+                if on_finished is not None:
+                    on_finished(self.slots[(k - lag) % D])
+            if D == 1 and k + 1 < nb:
+                self.front(vecs, k + 1, None if events is None else events[k + 1])
+        for k in range(max(0, nb - lag), nb):
+            self.finish(k)
+            if on_finished is not None:
+                on_finished(self.slots[k % D])
+        self.ctx.set_stream(self.main.cuda_stream)
 
     def step(self, vecs, with_hist=True):
-        """Serial form (depth-independent): one batch from vectors to R1/R2/NOE."""
+        """Serial form: one batch from vectors to R1/R2/NOE on the main stream."""
         s = self.slots[0]
+        self.ctx.set_stream(self.main.cuda_stream)
         self.stage_pack(vecs)
         self.stage_ct(s)
         if with_hist:

@@ -143,12 +143,18 @@ int sr_jomega_f64(sr_ctx *, const double *x, const double *y, double *out, int64
  *                1: NOE from the vector-averaged R1 (new API, :881-892)
  *   out          (E, nRes, 4, 2): {R1,R2,NOE,rho} x {weighted mean, weighted sigma}; sigma = 0 when B == 0
  *   Jout         (E, nRes, 5, 2) weighted mean/sigma of J(omega) or NULL (the --Jomega output)
+ *   stats        (E, nRes, 12) or NULL: sufficient statistics for CSA fitting.  The CSA enters the rates only
+ *                through f_CSA (proportional to csa^2): R1 = a1 + f_CSA*b1, R2 = a2 + f_CSA*b2 per vector, so
+ *                [a1, b1, Var a1, Cov(a1,b1), Var b1, a2, b2, Var a2, Cov(a2,b2), Var b2, N, Var N]
+ *                (weighted means / (co)variances over the vectors, N = 6 J(wH+wX) - J(wH-wX)) give the
+ *                weighted mean AND sigma of R1, R2 and the new-API NOE for ANY csa without touching the
+ *                2 592 bins again (rsCSA optimiser, spectral_densities.py:1371-1382, 1430-1447).
  * Host pointers. */
 int sr_jomega_relax_f64(sr_ctx *, int model, const double *D, int E, const double *omega, const double *f_DD,
                         const double *f_CSA, const double *time_fact, const double *gamma_ratio,
                         int nRes, int Kmax, const double *S2, const double *C, const double *tau, const int *nComps,
                         int B, const double *binvecs, const double *weights, int weights_on_device, int noe_mode,
-                        double *out, double *Jout);
+                        double *out, double *Jout, double *stats);
 
 /* ---- small device utilities ---------------------------------------------------------------
  * out[c*rows + r] = in[r*cols + c] (float64, device pointers): C(t) leaves kernel 1 as (lags, vectors)

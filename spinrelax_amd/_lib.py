@@ -54,7 +54,7 @@ SIGNATURES = {
     'sr_jomega_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     'sr_jomega_relax_f64': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                    c_int, c_int, c_void_p, c_void_p]),
+                                    c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

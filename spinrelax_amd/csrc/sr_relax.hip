@@ -21,7 +21,8 @@
 namespace {
 
 constexpr int kMaxK = 8;
-constexpr int kNQ = 10;      // R1, R2, NOE(old), rho, Nterm(6J4-J2), J0..J4
+constexpr int kNQ = 14;      // R1, R2, NOE(old), rho, Nterm(6J4-J2), J0..J4, a1, b1, a2, b2 (R = a + f_CSA*b)
+constexpr int kNC = 2;       // covariances: (a1,b1), (a2,b2)
 
 struct RelaxArgs {
     int model, E, nRes, Kmax, B, noe_mode;
@@ -30,7 +31,7 @@ struct RelaxArgs {
     const double *S2, *C, *tau;
     const int *nComps;
     const double *binvecs, *weights;
-    double *out, *Jout;
+    double *out, *Jout, *stats;
 };
 
 __device__ __forceinline__ double jomega(double x, double y) { return x / (x * x + y * y); }
@@ -47,26 +48,32 @@ __device__ __forceinline__ void quantities(const double *J, double fDD, double f
     q[3] = J1 / J0;
     q[4] = Nt;
     q[5] = J0; q[6] = J1; q[7] = J2; q[8] = J3; q[9] = J4;
+    // CSA enters only through f_CSA (proportional to csa^2): R1 = a1 + f_CSA*b1, R2 = a2 + f_CSA*b2
+    q[10] = tf * (fDD * (J2 + 3 * J1 + 6 * J4));
+    q[11] = tf * J1;
+    q[12] = tf * (0.5 * fDD * (4 * J0 + J2 + 3 * J1 + 6 * J4 + 6 * J3));
+    q[13] = tf * (1.0 / 6.0 * (4 * J0 + 3 * J1));
 }
 
-__device__ void block_sum(double *vals, int n, double *red, int tid)
+template <int CNT>
+__device__ __forceinline__ void block_sum(double *vals, double *red, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
-    for (int k = 0; k < n; ++k) {
-        double t = vals[k];
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
-        if (lane == 0) red[wave * 16 + k] = t;
+    for (int k = 0; k < CNT; ++k) {
+        const double t = sr_wave_sum_f64(vals[k]);
+        if (lane == 0) red[wave * 20 + k] = t;
     }
     __syncthreads();
-    for (int k = 0; k < n; ++k) vals[k] = ((red[k] + red[16 + k]) + red[32 + k]) + red[48 + k];
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) vals[k] = ((red[k] + red[20 + k]) + red[40 + k]) + red[60 + k];
     __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void k_relax(RelaxArgs a)
 {
     __shared__ double G[3][5];
-    __shared__ double red[64];
+    __shared__ double red[80];
     const int i = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
     const double *om = a.omega + e * 5;
     const double fDD = a.f_DD[e], fCSA = a.f_CSA[(int64_t)e * a.nRes + i], tf = a.time_fact[e], gr = a.gamma_ratio[e];
@@ -76,6 +83,7 @@ __global__ __launch_bounds__(256) void k_relax(RelaxArgs a)
     const bool prolate = a.D0 > a.D1;
     double *out = a.out + ((int64_t)e * a.nRes + i) * 8;
     double *Jout = a.Jout ? a.Jout + ((int64_t)e * a.nRes + i) * 10 : nullptr;
+    double *stats = a.stats ? a.stats + ((int64_t)e * a.nRes + i) * 12 : nullptr;
 
     if (tid < 15) {
         const int j = tid / 5, w = tid - j * 5;
@@ -117,6 +125,10 @@ __global__ __launch_bounds__(256) void k_relax(RelaxArgs a)
             quantities(J, fDD, fCSA, tf, gr, q);
             for (int k = 0; k < 4; ++k) { out[2 * k] = q[k]; out[2 * k + 1] = 0.0; }
             if (Jout) for (int w = 0; w < 5; ++w) { Jout[2 * w] = J[w]; Jout[2 * w + 1] = 0.0; }
+            if (stats) {
+                for (int k = 0; k < 12; ++k) stats[k] = 0.0;
+                stats[0] = q[10]; stats[1] = q[11]; stats[5] = q[12]; stats[6] = q[13]; stats[10] = q[4];
+            }
         }
         return;
     }
@@ -139,14 +151,14 @@ __global__ __launch_bounds__(256) void k_relax(RelaxArgs a)
             for (int k = 0; k < kNQ; ++k) s[k] += w_ * q[k];
             s[kNQ] += w_;
         }
-        block_sum(s, kNQ + 1, red, tid);
+        block_sum<kNQ + 1>(s, red, tid);
         wsum = s[kNQ];
         for (int k = 0; k < kNQ; ++k) mean[k] = s[k] / wsum;
     }
-    double var[kNQ];
-    {   // pass 2: weighted variance about the mean
-        double s[kNQ];
-        for (int k = 0; k < kNQ; ++k) s[k] = 0.0;
+    double var[kNQ + kNC];
+    {   // pass 2: weighted variance about the mean (+ the two covariances the closed-form CSA objective needs)
+        double s[kNQ + kNC];
+        for (int k = 0; k < kNQ + kNC; ++k) s[k] = 0.0;
         for (int b = tid; b < a.B; b += 256) {
             const double w_ = wgt ? wgt[b] : 1.0;
             const double *v = a.binvecs + (int64_t)b * 3;
@@ -157,9 +169,11 @@ __global__ __launch_bounds__(256) void k_relax(RelaxArgs a)
             for (int w = 0; w < 5; ++w) J[w] = A0 * G[0][w] + A1 * G[1][w] + A2 * G[2][w];
             quantities(J, fDD, fCSA, tf, gr, q);
             for (int k = 0; k < kNQ; ++k) { const double d = q[k] - mean[k]; s[k] += w_ * (d * d); }
+            s[kNQ] += w_ * ((q[10] - mean[10]) * (q[11] - mean[11]));
+            s[kNQ + 1] += w_ * ((q[12] - mean[12]) * (q[13] - mean[13]));
         }
-        block_sum(s, kNQ, red, tid);
-        for (int k = 0; k < kNQ; ++k) var[k] = s[k] / wsum;
+        block_sum<kNQ + kNC>(s, red, tid);
+        for (int k = 0; k < kNQ + kNC; ++k) var[k] = s[k] / wsum;
     }
     if (tid == 0) {
         out[0] = mean[0]; out[1] = sqrt(var[0]);
@@ -174,6 +188,12 @@ __global__ __launch_bounds__(256) void k_relax(RelaxArgs a)
         }
         out[6] = mean[3]; out[7] = sqrt(var[3]);
         if (Jout) for (int w = 0; w < 5; ++w) { Jout[2 * w] = mean[5 + w]; Jout[2 * w + 1] = sqrt(var[5 + w]); }
+        if (stats) {
+            // [a1, b1, Var a1, Cov(a1,b1), Var b1, a2, b2, Var a2, Cov(a2,b2), Var b2, N, Var N]
+            stats[0] = mean[10]; stats[1] = mean[11]; stats[2] = var[10]; stats[3] = var[kNQ]; stats[4] = var[11];
+            stats[5] = mean[12]; stats[6] = mean[13]; stats[7] = var[12]; stats[8] = var[kNQ + 1]; stats[9] = var[13];
+            stats[10] = mean[4]; stats[11] = var[4];
+        }
     }
 }
 
@@ -219,7 +239,7 @@ int sr_jomega_relax_f64(sr_ctx *ctx, int model, const double *D, int E, const do
                         const double *f_CSA, const double *time_fact, const double *gamma_ratio, int nRes, int Kmax,
                         const double *S2, const double *C, const double *tau, const int *nComps, int B,
                         const double *binvecs, const double *weights, int weights_on_device, int noe_mode, double *out,
-                        double *Jout)
+                        double *Jout, double *stats)
 {
     SR_CHECK_CTX(ctx);
     SR_REQUIRE(model >= 0 && model <= 2, -3, "sr_jomega_relax_f64: model must be 0, 1 or 2");
@@ -241,7 +261,8 @@ int sr_jomega_relax_f64(sr_ctx *ctx, int model, const double *D, int E, const do
     int *ncomp_d = (int *)sr_workspace(ctx, SR_WS_IN1, nR * sizeof(int));
     double *out_d = (double *)sr_workspace(ctx, SR_WS_OUT0, nE * nR * 8 * sizeof(double));
     double *J_d = Jout ? (double *)sr_workspace(ctx, SR_WS_OUT1, nE * nR * 10 * sizeof(double)) : nullptr;
-    if (!stage || !ncomp_d || !out_d || (Jout && !J_d)) return -5;
+    double *st_d = stats ? (double *)sr_workspace(ctx, SR_WS_OUT2, nE * nR * 12 * sizeof(double)) : nullptr;
+    if (!stage || !ncomp_d || !out_d || (Jout && !J_d) || (stats && !st_d)) return -5;
     RelaxArgs a;
     a.model = model; a.E = E; a.nRes = nRes; a.Kmax = Kmax; a.B = (model == 2) ? B : 0; a.noe_mode = noe_mode;
     a.D0 = D ? D[0] : 0.0;
@@ -272,10 +293,12 @@ int sr_jomega_relax_f64(sr_ctx *ctx, int model, const double *D, int E, const do
     a.nComps = ncomp_d;
     a.out = out_d;
     a.Jout = J_d;
+    a.stats = st_d;
     hipLaunchKernelGGL(k_relax, dim3((unsigned)nRes, (unsigned)E), dim3(256), 0, ctx->stream, a);
     SR_HIP(hipGetLastError());
     SR_HIP(hipMemcpyAsync(out, out_d, nE * nR * 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (Jout) SR_HIP(hipMemcpyAsync(Jout, J_d, nE * nR * 10 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (stats) SR_HIP(hipMemcpyAsync(stats, st_d, nE * nR * 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SR_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -197,7 +197,7 @@ class Context:
         return out
 
     def relax(self, model, D, omega, f_DD, f_CSA, time_fact, gamma_ratio, S2, C, tau, nComps,
-              binvecs=None, weights=None, resvecs=None, noe_mode=0, want_J=False, weights_dev_ptr=None):
+              binvecs=None, weights=None, resvecs=None, noe_mode=0, want_J=False, weights_dev_ptr=None, want_stats=False):
         """model 0 direct / 1 sphere (D=[Diso]) / 2 symmetric top (D=[Dpar, Dperp]).
         Symmetric top: either `binvecs` (B,3) shared by all residues with optional `weights` (nRes,B), or
         `resvecs` (nRes,3), one vector per residue.  Returns out (E, nRes, 4, 2) = [R1,R2,NOE,rho] x
@@ -234,11 +234,14 @@ class Context:
                 raise ValueError('symmetric-top model needs binvecs or resvecs')
         out = np.empty((E, nRes, 4, 2))
         J = np.empty((E, nRes, 5, 2)) if want_J else None
+        stats = np.empty((E, nRes, 12)) if want_stats else None
         check(self.lib.sr_jomega_relax_f64(self.h, int(model), _ptr(Dd), E, _ptr(omega), _ptr(f_DD), _ptr(f_CSA),
                                            _ptr(time_fact), _ptr(gamma_ratio), nRes, Kmax, _ptr(S2), _ptr(C), _ptr(tau),
                                            _ptr(nc), B, _ptr(bv), weights_dev_ptr if weights_dev_ptr else _ptr(w),
-                                           1 if weights_dev_ptr else 0, int(noe_mode), _ptr(out), _ptr(J)),
+                                           1 if weights_dev_ptr else 0, int(noe_mode), _ptr(out), _ptr(J), _ptr(stats)),
               'sr_jomega_relax_f64')
+        if want_stats:
+            return out, J, stats
         return out, J
 
 

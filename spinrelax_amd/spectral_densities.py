@@ -314,3 +314,11 @@ def read_vector_distribution_from_file(fileName):
     else:
         print("    ...converted input phi_theta data to vecXH, whose shape is:", vecs.shape)
     return resIDs, vecs, weights
+
+
+# the new class API (angularFrequencies, globalRotationalDiffusion_*, spinRelaxationR1/R2/NOE,
+# spinRelaxationExperiments) lives in spin_relaxation.py; re-exported here under the reference's module name
+from .spin_relaxation import (angularFrequencies, gyromagMultiCSA, globalRotationalDiffusion_Base,      # noqa: E402,F401
+                              globalRotationalDiffusion_Isotropic, globalRotationalDiffusion_Axisymmetric,
+                              spinRelaxationBase, spinRelaxationR1, spinRelaxationR2, spinRelaxationNOE,
+                              spinRelaxationExperiments)

@@ -1,0 +1,124 @@
+"""
+GPU tests of the new class API and the multi-field / rsCSA optimiser against
+what the reference's spinRelaxationExperiments produced (tests/golden/cfg1_rscsa.npz, cfg1_relax.npz).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT, golden, relerr
+from spinrelax_amd import synth
+from spinrelax_amd import fitting_Ct_functions as fitCt
+from spinrelax_amd import spectral_densities as sd
+
+pytestmark = pytest.mark.gpu
+
+
+def write_experiments(g, tmpdir, names):
+    files = []
+    for k in range(len(g['expt_kind'])):
+        kind, MHz = str(g['expt_kind'][k]), float(g['expt_MHz'][k])
+        fn = os.path.join(tmpdir, 'expt_%s_%d.dat' % (kind, round(MHz)))
+        with open(fn, 'w') as fp:
+            print('# Type %s' % kind, file=fp)
+            print('# NucleiA 15N', file=fp)
+            print('# NucleiB 1H', file=fp)
+            print('# Frequency %.3f' % MHz, file=fp)
+            for nm, v, e in zip(names, g['expt_vals'][k], g['expt_errs'][k]):
+                print('%s %.12g %.12g' % (nm, v, e), file=fp)
+        files.append(fn)
+    return files
+
+
+def build(tmp_path):
+    g = golden('cfg1_rscsa.npz')
+    localCt = fitCt.read_fittedCt_parameters(os.path.join(GOLD, 'cfg1_fittedCt.dat'))
+    grd = sd.globalRotationalDiffusion_Axisymmetric(D=[synth.DISO, synth.DANI])
+    grd.import_frame_vectors_npz(os.path.join(GOLD, 'cfg1_vecHistogram.npz'))
+    ex = sd.spinRelaxationExperiments(grd, localCt)
+    for f in write_experiments(g, str(tmp_path), localCt.get_names()):
+        ex.add_experiment(f)
+    ex.set_global_zeta(synth.ZETA)
+    ex.map_experiment_peaknames_to_models()
+    return g, ex
+
+
+def test_new_api_eval_all_vs_reference(tmp_path):
+    r = golden('cfg1_relax.npz')
+    g, ex = build(tmp_path)
+    ex.eval_all()
+    for k, sp in enumerate(ex.spinrelax):
+        fi = list(r['fields']).index(float(g['expt_MHz'][k]))
+        kind = str(g['expt_kind'][k])
+        assert relerr(sp.values, r['new_%s_val_%d' % (kind, fi)]) < 1e-11
+        assert relerr(sp.errors, r['new_%s_err_%d' % (kind, fi)]) < 1e-8
+        np.testing.assert_array_equal(sp.angFreq.omega, r['new_omega_%d' % fi])
+    assert ex.spinrelax[0].angFreq.get_factor_DD() == float(r['new_fDD'])
+
+
+def test_rscsa_objective_closed_form_vs_reference(tmp_path):
+    """the objective the reference evaluates by brute force over the 2592 bins, from 12 statistics per (e, i)"""
+    g, ex = build(tmp_path)
+    ex.parse_optimisation_params(['rsCSA'])
+    ex.eval_all()
+    stats = ex.rscsa_statistics()
+    cover = ex.mapExptCoverage[0]
+    for csa, ref in zip(g['obj_grid'], g['obj_res0']):
+        chisq = 0.0
+        for e, peak in cover:
+            v, dv = ex.rscsa_closed_form(stats, e, 0, float(csa))
+            t, dt = ex.data[e]['y'][peak], ex.data[e]['dy'][peak]
+            chisq += (v - t) ** 2 / (dv ** 2 + dt ** 2)
+        # near the planted CSA the objective is ~1e-21 (pure rounding): absolute floor next to the relative bar
+        assert abs(chisq / len(cover) - ref) <= 1e-9 * ref + 1e-16
+
+
+def test_rscsa_optimisation_vs_reference(tmp_path):
+    g, ex = build(tmp_path)
+    ex.parse_optimisation_params(['rsCSA'])
+    chisq = ex.perform_optimisation(maxCycles=10, tol=1e-6)
+    fitted = np.array(ex.get_first_csa())
+    # fitted CSA: the reference's own values (same Powell calls on an objective equal to 1e-9) ...
+    np.testing.assert_allclose(fitted, g['fitted'], rtol=1e-6)
+    # ... which recover the planted CSA
+    np.testing.assert_allclose(fitted, g['planted'], rtol=1e-5)
+    assert abs(chisq - float(g['chisq'])) <= 1e-6 * max(abs(float(g['chisq'])), 1e-12) + 1e-15
+    for k, sp in enumerate(ex.spinrelax):
+        assert relerr(sp.values, g['vals_after'][k]) < 1e-6
+    # the exported xvg of the first experiment equals the reference's file
+    ex.export_xvg(str(tmp_path / 'out'), bIncludeExpt=True)
+    import json
+    name = json.load(open(os.path.join(GOLD, 'MANIFEST.json')))['cfg1_xvg_name']
+    mine = open(str(tmp_path / name)).read().split('\n')
+    ref = open(os.path.join(GOLD, 'cfg1_' + name)).read().split('\n')
+    assert len(mine) == len(ref)
+    assert sum(a == b for a, b in zip(mine, ref)) >= len(ref) - 3          # %g text; allow last-digit flips
+
+
+def test_global_Diso_optimisation_recovers_truth(tmp_path):
+    """experiments generated at (Diso, planted CSA); start the global search from a perturbed Diso"""
+    g, ex = build(tmp_path)
+    ex.initialise_CSA_array(ex.localCtModels.get_names(), g['planted'])
+    ex.set_global_Diso(synth.DISO * 1.08)
+    ex.parse_optimisation_params(['Diso'])
+    chisq = ex.perform_optimisation()
+    assert abs(ex.get_global_Diso() / synth.DISO - 1) < 2e-4
+    assert chisq < 1e-4
+
+
+def test_multi_field_script(tmp_path):
+    g = golden('cfg1_rscsa.npz')
+    localCt = fitCt.read_fittedCt_parameters(os.path.join(GOLD, 'cfg1_fittedCt.dat'))
+    files = write_experiments(g, str(tmp_path), localCt.get_names())
+    out = str(tmp_path / 'mf')
+    cmd = [sys.executable, os.path.join(ROOT, 'scripts', 'calculate-relaxations-multi-field.py'), '-f',
+           os.path.join(GOLD, 'cfg1_fittedCt.dat'), '-o', out, '--distfn', os.path.join(GOLD, 'cfg1_vecHistogram.npz'),
+           '-D', '%g' % synth.DISO, '--aniso', '%g' % synth.DANI, '--opt', 'rsCSA'] + files
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode()
+    csa = np.loadtxt(out + '_CSA_opt.dat')
+    np.testing.assert_allclose(csa[:, 1], g['fitted'], rtol=6e-6)             # %g keeps 6 significant digits
+    assert len([f for f in os.listdir(str(tmp_path)) if f.startswith('mf_15N1H_') and f.endswith('.xvg')]) == 9

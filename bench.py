@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--vectors', type=int, default=None, help='vectors per GPU (default: the config value)')
     ap.add_argument('--depth', type=int, default=4, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
+    ap.add_argument('--all-ranks-on-device0', action='store_true', help='rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)')
     ap.add_argument('--stage-breakdown', action='store_true', help='after the timed loop, print a synchronised per-stage wall-time breakdown to stderr (diagnostic)')
     ap.add_argument('--cpu-sample-vectors', type=int, default=8)
     return ap.parse_args()
@@ -109,9 +111,14 @@ def main():
     vecs_host = synth.synth_vectors_parallel(s['frames'], V, s['seed'], v0=rank * V)
     gen_s = time.time() - t0
 
+    if args.all_ranks_on_device0:
+        local = 0
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+        if args.backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend=args.backend)
     if args.gpus != world and rank == 0:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local)

@@ -10,6 +10,11 @@
 //   mean vector                 calculate-Ct-from-traj.py:579-583
 //   S2 outer products           calculate-Ct-from-traj.py:96-145
 //
+// Binning cost: float64 atan2 / acos / cos for every sample made the kernel FP64-issue bound (0.75 ms for cfg3,
+// 10 % of the HBM roofline).  A float32 estimate now classifies every sample that is clearly inside a bin; only
+// samples within a guard band of a bin edge (and NaNs) take the float64 path, so the counts stay bit-identical
+// to numpy's (tests/test_gpu_parity.py::test_vechist_*).
+//
 // Work decomposition: grid = (frame ranges, vectors).  A workgroup owns one vector and a frame range
 // that lies inside one S2 block; its histogram lives in LDS as 32-bit counters (nphi*ncos*4 B = 10 KB
 // for 72x36) and is flushed with integer atomics (deterministic); the 9 float64 sums go to a
@@ -63,6 +68,58 @@ __device__ __forceinline__ void rotate_q(double qw, double qx, double qy, double
     oz = (bz + bz) + vz;
 }
 
+// Accumulator state of one thread
+struct VhAcc {
+    double sx, sy, sz, oxx, oyy, ozz, oxy, oxz, oyz;
+};
+
+// exact (reference-order, float64) bin coordinates of a rotated vector: xyz_to_rtp + cos(theta)
+__device__ __noinline__ void exact_phi_cos(double x, double y, double z, double &phi, double &c)
+{
+#pragma clang fp contract(off)
+    const double r = sqrt((x * x + y * y) + z * z);
+    phi = atan2(y, x);
+    c = cos(acos(z / r));
+}
+
+// One sample: rotate (float64, reference operation order), accumulate the sums, histogram it.
+// Binning: a float32 estimate of (phi, cos theta) decides the bin when it lies at least kEdgeGuard bin widths
+// away from both edges of that bin -- the estimate is good to < 1e-6 rad / 5e-7, the guard band is 1.7e-5 rad /
+// 1.1e-5, so the decision is the one numpy's searchsorted makes on the float64 values; otherwise (4e-4 of the
+// samples, and every NaN / out-of-range value) the float64 atan2 / acos / cos path decides exactly like before.
+constexpr float kEdgeGuard = 2e-4f;
+
+__device__ __forceinline__ void vh_sample(const VhArgs &a, float xf, float yf, float zf, bool in_block,
+                                          const double *ephi, const double *ecos, unsigned int *h, VhAcc &s,
+                                          float phi_scale, float cos_scale)
+{
+    double x = (double)xf, y = (double)yf, z = (double)zf;
+    if (a.rotate) {
+        double rx, ry, rz;
+        rotate_q(a.qw, a.qx, a.qy, a.qz, x, y, z, rx, ry, rz);
+        x = rx; y = ry; z = rz;
+    }
+    s.sx += x; s.sy += y; s.sz += z;
+    if (in_block) {
+        s.oxx += x * x; s.oyy += y * y; s.ozz += z * z;
+        s.oxy += x * y; s.oxz += x * z; s.oyz += y * z;
+    }
+    const float fx = (float)x, fy = (float)y, fz = (float)z;
+    const float tp = (atan2f(fy, fx) + 3.14159265358979f) * phi_scale;          // position in phi-bin units
+    const float tc = (fz * rsqrtf((fx * fx + fy * fy) + fz * fz) + 1.0f) * cos_scale;
+    const float kpf = floorf(tp), kcf = floorf(tc);
+    int kp = (int)kpf, kc = (int)kcf;
+    const bool sure = (tp - kpf > kEdgeGuard) && (tp - kpf < 1.0f - kEdgeGuard) && (tc - kcf > kEdgeGuard) &&
+                      (tc - kcf < 1.0f - kEdgeGuard) && kp >= 0 && kp < a.nphi && kc >= 0 && kc < a.ncos;
+    if (!sure) {
+        double phi, c;
+        exact_phi_cos(x, y, z, phi, c);
+        kp = np_bin(ephi, a.nphi, phi);
+        kc = np_bin(ecos, a.ncos, c);
+    }
+    if (kp >= 0 && kc >= 0) atomicAdd(&h[kp * a.ncos + kc], 1u);
+}
+
 __global__ __launch_bounds__(256) void k_vechist(VhArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -79,6 +136,9 @@ __global__ __launch_bounds__(256) void k_vechist(VhArgs a)
     for (int i = tid; i < nbins; i += 256) h[i] = 0u;
     __syncthreads();
     const double *ephi = edges, *ecos = edges + a.nphi + 1;
+    // the float32 estimate assumes the uniform numpy.linspace edges of calculate-Ct-from-traj.py:618
+    const float phi_scale = (float)((double)a.nphi / (ephi[a.nphi] - ephi[0]));
+    const float cos_scale = (float)((double)a.ncos / (ecos[a.ncos] - ecos[0]));
 
     int64_t start, end;
     bool in_block;
@@ -96,39 +156,32 @@ __global__ __launch_bounds__(256) void k_vechist(VhArgs a)
     const float *py = px + a.Npad;
     const float *pz = py + a.Npad;
 
-    double sx = 0, sy = 0, sz = 0, oxx = 0, oyy = 0, ozz = 0, oxy = 0, oxz = 0, oyz = 0;
-    for (int64_t n = start + tid; n < end; n += 256) {
-        double x = (double)px[n], y = (double)py[n], z = (double)pz[n];
-        if (a.rotate) {
-            double rx, ry, rz;
-            rotate_q(a.qw, a.qx, a.qy, a.qz, x, y, z, rx, ry, rz);
-            x = rx; y = ry; z = rz;
+    VhAcc s = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t n0 = start;
+    if ((start & 3) == 0) {
+        // 16-byte loads: 4 consecutive frames per thread
+        const int64_t nvec = (end - start) >> 2;
+        for (int64_t q = tid; q < nvec; q += 256) {
+            const int64_t n = start + (q << 2);
+            const float4 X = *reinterpret_cast<const float4 *>(px + n);
+            const float4 Y = *reinterpret_cast<const float4 *>(py + n);
+            const float4 Z = *reinterpret_cast<const float4 *>(pz + n);
+            vh_sample(a, X.x, Y.x, Z.x, in_block, ephi, ecos, h, s, phi_scale, cos_scale);
+            vh_sample(a, X.y, Y.y, Z.y, in_block, ephi, ecos, h, s, phi_scale, cos_scale);
+            vh_sample(a, X.z, Y.z, Z.z, in_block, ephi, ecos, h, s, phi_scale, cos_scale);
+            vh_sample(a, X.w, Y.w, Z.w, in_block, ephi, ecos, h, s, phi_scale, cos_scale);
         }
-        sx += x; sy += y; sz += z;
-        if (in_block) {
-            oxx += x * x; oyy += y * y; ozz += z * z;
-            oxy += x * y; oxz += x * z; oyz += y * z;
-        }
-        double r, phi, c;
-        {
-#pragma clang fp contract(off)
-            r = sqrt((x * x + y * y) + z * z);
-            phi = atan2(y, x);
-            c = cos(acos(z / r));
-        }
-        const int kp = np_bin(ephi, a.nphi, phi);
-        const int kc = np_bin(ecos, a.ncos, c);
-        if (kp >= 0 && kc >= 0) atomicAdd(&h[kp * a.ncos + kc], 1u);
+        n0 = start + (nvec << 2);
     }
+    for (int64_t n = n0 + tid; n < end; n += 256)
+        vh_sample(a, px[n], py[n], pz[n], in_block, ephi, ecos, h, s, phi_scale, cos_scale);
 
-    // block reduction of the 9 sums (fixed order: lanes by butterfly, then waves 0..3)
-    double vals[9] = {sx, sy, sz, oxx, oyy, ozz, oxy, oxz, oyz};
+    // block reduction of the 9 sums (fixed order: lanes by DPP butterfly, then waves 0..3)
+    double vals[9] = {s.sx, s.sy, s.sz, s.oxx, s.oyy, s.ozz, s.oxy, s.oxz, s.oyz};
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-        double t = vals[k];
-#pragma unroll
-        for (int msk = 32; msk >= 1; msk >>= 1) t += __shfl_xor(t, msk, 64);
+        const double t = sr_wave_sum_f64(vals[k]);
         if (lane == 0) red[wave * 9 + k] = t;
     }
     __syncthreads();

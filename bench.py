@@ -43,6 +43,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', type=str, default='cfg3', choices=['cfg2', 'cfg3'])
     ap.add_argument('--vectors', type=int, default=None, help='vectors per GPU (default: the config value)')
+    ap.add_argument('--reserve-cus', type=int, default=16, help='CUs kept free of the C(t)/histogram kernels for the latency-bound fit kernels (CU-masked stream; 0 = no partition)')
+    ap.add_argument('--fits-on-reserved-only', action='store_true', help='confine the fit kernels to the reserved CUs')
     ap.add_argument('--depth', type=int, default=4, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
@@ -125,14 +127,16 @@ def main():
     dev = torch.device('cuda', local)
 
     vecs = torch.from_numpy(vecs_host).to(dev)           # resident in HBM before the timed region
-    stream = torch.cuda.Stream(device=dev)
     ctx = Context(local)
-    ctx.set_stream(stream.cuda_stream)
     triples = synth.exact_triples(s['R'], s['F'], V)
+    pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], q_rot=q, Diso=synth.DISO, aniso=aniso,
+                          field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA, depth=args.depth,
+                          stream=torch.cuda.Stream(device=dev), reserve_cus=args.reserve_cus,
+                          fits_on_reserved_only=args.fits_on_reserved_only)
+    stream = pipe.main
+    ctx.set_stream(stream.cuda_stream)
 
     with torch.cuda.stream(stream):
-        pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], q_rot=q, Diso=synth.DISO, aniso=aniso,
-                              field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA, depth=args.depth, stream=stream)
 
         def gather_results(slot):
             if world == 1:
@@ -205,7 +209,7 @@ def main():
             'config': {'workload': 'BASELINE cfg%d per GPU: %d frames x %d vectors, %d chunks x %d frames, %d lags, '
                                    '%s, fits 2/3/5/7/9 params, 1 field' % (cfg, s['frames'], V, s['R'], s['F'], s['L'],
                                                                            'axisymmetric D + q_ext + 72x36 histogram' if cfg == 3 else 'isotropic D'),
-                       'vectors_per_gpu': V, 'exact_triples_per_gpu': triples, 'sharding': 'vectors (no data-path collective; all-gather of results)', 'batches_in_flight': pipe.depth},
+                       'vectors_per_gpu': V, 'exact_triples_per_gpu': triples, 'sharding': 'vectors (no data-path collective; all-gather of results)', 'batches_in_flight': pipe.depth, 'cus_reserved_for_fits': pipe.reserve_cus},
             'roofline': {'bound': 'valu-fp32 (non-MFMA vector FMA; FP32 MFMA peak is the same 157.3)', 'kernel': 'k_ct_palmer',
                          'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS,
                          'traffic': None, 'kernel_ms': ct_ms, 'flop_per_triple': 8,

@@ -38,6 +38,13 @@ sr_ctx      *sr_create(int device);                 /* NULL on failure (see sr_l
 void         sr_destroy(sr_ctx *);
 int          sr_set_stream(sr_ctx *, void *hip_stream);   /* hipStream_t; NULL = default stream  */
 int          sr_sync(sr_ctx *);
+/* Streams that partition the chip.  The fits of fitting_Ct_functions.py:278-345 are a latency chain of small
+ * launches; queued behind a C(t) launch that fills every CU they starve (queue priority does not pre-empt
+ * resident workgroups).  sr_stream_create returns a hipStream_t whose kernels may only run on the CUs whose bit is
+ * set in cu_mask (n_words 32-bit words, bit i of word w = CU 32*w+i in the runtime's numbering; NULL / 0 words =
+ * all CUs); priority as hipStreamCreateWithPriority (lower = more urgent, 0 = default). */
+int          sr_stream_create(sr_ctx *, const uint32_t *cu_mask, int n_words, int priority, void **stream_out);
+int          sr_stream_destroy(sr_ctx *, void *hip_stream);
 int          sr_device_info(sr_ctx *, int *n_cu, int64_t *hbm_bytes, int *lds_per_cu, char *name, int name_len);
 void        *sr_malloc(sr_ctx *, size_t bytes);     /* device memory                              */
 int          sr_free(sr_ctx *, void *dev_ptr);
@@ -122,6 +129,33 @@ int sr_expfit_lm_f64_dev(sr_ctx *, const double *t, const double *C, const doubl
                          const double *p0, double tau_max, int max_iter, const unsigned char *skip, double *work,
                          double *popt, double *pcov, double *chisq, int *status, int *n_iter);
 
+/* The whole model-order search of optimised_curve_fitting (fitting_Ct_functions.py:278-304) in ONE launch, one
+ * workgroup per residue: for every order in `orders` (numbers of parameters, e.g. 2,3,5,7,9; host array, at most 8)
+ * the initial guess of initialise_for_fit_advanced (:359-374), the bounded fit of conduct_curve_fitting (:306-345),
+ * its three quality flags and the accept / reject rule (chi_threshold = chiSqThreshold, 0.5 in the reference).
+ * All other pointers are DEVICE pointers.
+ *   tau_guess   (tau_guess_rows, sum orders[j]/2): the log-spaced tau guesses of :361-362 for every order, one after
+ *               the other; tau_guess_rows = 1 (every residue has the same time axis) or nRes
+ *   work        (nRes*L doubles) or NULL: only used when a residue (3*L doubles) does not fit into LDS
+ *   popt, dP    (nOrders, nRes, Pmax) with Pmax = max(orders): optimum and sqrt(diag(pcov)) of every attempted order
+ *   chisq       (nOrders, nRes) calc_chiSq of the fit, +inf when the solver failed
+ *   status,nfev (nOrders, nRes); status = -100: order not attempted (the search had already stopped)
+ *   best        (nRes) index into orders of the accepted model, -1 = no satisfactory fit
+ *   sel_*       the accepted model with its components sorted by tau (sort_components :203-209): S2 (nRes),
+ *               C and tau (nRes, Pmax/2; unused entries 0 and 1), chi (nRes, NaN if none), K (nRes) = components
+ * The launch is asynchronous on the context's stream. */
+int sr_expfit_order_search_f64_dev(sr_ctx *, const double *t, const double *C, const double *sigma, int nRes, int L,
+                                   const int *orders, int nOrders, const double *tau_guess, int tau_guess_rows,
+                                   double tau_max, double chi_threshold, double *work, double *popt, double *dP,
+                                   double *chisq, int *status, int *nfev, int *best, double *sel_S2, double *sel_C,
+                                   double *sel_tau, double *sel_chi, int *sel_K);
+/* the same with HOST pointers throughout (staged through the context's work space, synchronous) */
+int sr_expfit_order_search_f64(sr_ctx *, const double *t, const double *C, const double *sigma, int nRes, int L,
+                               const int *orders, int nOrders, const double *tau_guess, int tau_guess_rows,
+                               double tau_max, double chi_threshold, double *popt, double *dP, double *chisq,
+                               int *status, int *nfev, int *best, double *sel_S2, double *sel_C, double *sel_tau,
+                               double *sel_chi, int *sel_K);
+
 /* ---- kernel 3a: J(omega) and R1/R2/NOE/rho ----------------------------------------------
  * sr_jomega_f64: elementwise x/(x*x+y*y), the double loop of Jomega/Jomega.c:49-66, evaluated on the
  * GPU (host pointers; n elements, both inputs already broadcast by the caller). */
@@ -155,6 +189,15 @@ int sr_jomega_relax_f64(sr_ctx *, int model, const double *D, int E, const doubl
                         int nRes, int Kmax, const double *S2, const double *C, const double *tau, const int *nComps,
                         int B, const double *binvecs, const double *weights, int weights_on_device, int noe_mode,
                         double *out, double *Jout, double *stats);
+/* Device-pointer form for a pipeline that never leaves the GPU: every array argument is a DEVICE pointer (D stays a
+ * host array of 1 or 2 numbers), nComps[i] must be within 0..Kmax (not checked), S2 and C are multiplied by zeta on
+ * load (the reference scales the fitted model by zeta first, calculate-relaxations-from-Ct.py:747-750; pass 1.0 for
+ * already-scaled input); asynchronous on the context's stream. */
+int sr_jomega_relax_f64_dev(sr_ctx *, int model, const double *D, int E, const double *omega, const double *f_DD,
+                            const double *f_CSA, const double *time_fact, const double *gamma_ratio,
+                            int nRes, int Kmax, double zeta, const double *S2, const double *C, const double *tau,
+                            const int *nComps, int B, const double *binvecs, const double *weights, int noe_mode,
+                            double *out, double *Jout, double *stats);
 
 /* ---- small device utilities ---------------------------------------------------------------
  * out[c*rows + r] = in[r*cols + c] (float64, device pointers): C(t) leaves kernel 1 as (lags, vectors)

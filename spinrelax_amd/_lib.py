@@ -24,6 +24,8 @@ SIGNATURES = {
     'sr_destroy': (None, [c_void_p]),
     'sr_set_stream': (c_int, [c_void_p, c_void_p]),
     'sr_sync': (c_int, [c_void_p]),
+    'sr_stream_create': (c_int, [c_void_p, POINTER(ctypes.c_uint32), c_int, c_int, POINTER(c_void_p)]),
+    'sr_stream_destroy': (c_int, [c_void_p, c_void_p]),
     'sr_device_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int64), POINTER(c_int), c_char_p, c_int]),
     'sr_malloc': (c_void_p, [c_void_p, c_size_t]),
     'sr_free': (c_int, [c_void_p, c_void_p]),
@@ -50,6 +52,19 @@ SIGNATURES = {
                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'sr_expfit_lm_f64_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_double,
                                      c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    # (ctx, t, C, sigma, nRes, L, orders, nOrders, tau_guess, tau_rows, tau_max, chi_thr, work, popt, dP, chisq, status,
+    #  nfev, best, sel_S2, sel_C, sel_tau, sel_chi, sel_K)
+    'sr_expfit_order_search_f64_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                               c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'sr_expfit_order_search_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                           c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    # (ctx, model, D, E, omega, f_DD, f_CSA, time_fact, gamma_ratio, nRes, Kmax, zeta, S2, C, tau, nComps, B, binvecs,
+    #  weights, noe_mode, out, Jout, stats)
+    'sr_jomega_relax_f64_dev': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                        c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'sr_transpose_f64_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'sr_jomega_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     'sr_jomega_relax_f64': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -93,6 +93,33 @@ int sr_set_stream(sr_ctx *ctx, void *hip_stream)
     return 0;
 }
 
+int sr_stream_create(sr_ctx *ctx, const uint32_t *cu_mask, int n_words, int priority, void **stream_out)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(stream_out != nullptr, -2, "sr_stream_create: stream_out is NULL");
+    SR_REQUIRE(n_words >= 0 && n_words <= 32, -2, "sr_stream_create: n_words out of range");
+    hipStream_t st = nullptr;
+    if (cu_mask && n_words > 0) {
+        bool any = false;
+        for (int i = 0; i < n_words; ++i) any = any || cu_mask[i] != 0u;
+        SR_REQUIRE(any, -2, "sr_stream_create: empty CU mask");
+        SR_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, cu_mask));
+    } else {
+        SR_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority));
+    }
+    *stream_out = (void *)st;
+    return 0;
+}
+
+int sr_stream_destroy(sr_ctx *ctx, void *hip_stream)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(hip_stream != nullptr, -2, "sr_stream_destroy: NULL stream");
+    if (ctx->stream == (hipStream_t)hip_stream) ctx->stream = nullptr;
+    SR_HIP(hipStreamDestroy((hipStream_t)hip_stream));
+    return 0;
+}
+
 int sr_sync(sr_ctx *ctx)
 {
     SR_CHECK_CTX(ctx);

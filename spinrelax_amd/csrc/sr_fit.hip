@@ -38,7 +38,7 @@ struct FitArgs {
     double ftol, xtol, gtol;
     double *popt, *pcov, *chisq;      // (nRes,N), (nRes,N,N), (nRes)
     int *status, *nfev;               // (nRes)
-    double *fws;                      // (nRes, 2, L) residual work space
+    double *fws;                      // (nRes, L) weights, only used when a residue does not fit into LDS
 };
 
 __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
@@ -396,168 +396,205 @@ __device__ __forceinline__ void strictly_feasible(double *x, const double *lb, c
     }
 }
 
-template <int N, int W>
-struct Trf {
-    static constexpr int K = N / 2;
-    static constexpr int NT = N * (N + 1) / 2;
-    static constexpr int NTH = W * 64;
-    using M = Model<N>;
+extern __shared__ __align__(16) double fit_smem[];
 
-    const double *t, *y, *sg;
+// Per-residue data access.  LDS = true: t, y and the weights 1/sigma of the residue live in LDS for the whole
+// solve (3*L doubles after the reduction scratch) -- every model evaluation used to re-read them from L2/HBM
+// with one wave per SIMD and nothing to hide the latency behind, which was most of the ~12 us an iteration cost
+// even at n = 2.  LDS = false (L too long for LDS): global memory, weights precomputed into the work array.
+constexpr int kRedStride = kNmax * (kNmax + 1) / 2 + kNmax + 2;   // doubles per wave in the reduction scratch
+
+template <int W, bool LDS>
+struct Residue {
+    static constexpr int NTH = W * 64;
+    static constexpr int RED = W * kRedStride;
+
+    const double *tg, *yg, *wg;   // global (LDS == false)
+    const double *sg;             // sigma of this residue (global) or null
     int L, tid;
-    double *red;          // LDS: W x (NT + N + 2) partials
+
+    __device__ __forceinline__ double *red() const { return fit_smem; }
+    __device__ __forceinline__ double ld_t(int l) const { return LDS ? fit_smem[RED + l] : tg[l]; }
+    __device__ __forceinline__ double ld_y(int l) const { return LDS ? fit_smem[RED + L + l] : yg[l]; }
+    __device__ __forceinline__ double ld_w(int l) const { return LDS ? fit_smem[RED + 2 * L + l] : wg[l]; }
+
+    // stage the residue: weights 1/sigma (curve_fit: transform = 1/sigma, _minpack_py.py:985), t, y
+    __device__ void stage(const double *t, const double *y, const double *sg_, double *wbuf)
+    {
+        sg = sg_;
+        for (int l = tid; l < L; l += NTH) {
+            const double w = sg ? 1.0 / sg[l] : 1.0;
+            if (LDS) {
+                fit_smem[RED + l] = t[l];
+                fit_smem[RED + L + l] = y[l];
+                fit_smem[RED + 2 * L + l] = w;
+            } else {
+                wbuf[l] = w;
+            }
+        }
+        tg = t; yg = y; wg = wbuf;
+        __syncthreads();
+    }
 
     // sum of v over the workgroup, identical in every thread (fixed combination order)
     template <int CNT>
     __device__ __forceinline__ void block_sums(double *vals) const
     {
         const int lane = tid & 63, wave = tid >> 6;
+        double *r = red();
 #pragma unroll
         for (int k = 0; k < CNT; ++k) {
             const double w = wsum(vals[k]);
-            if (lane == 0) red[wave * (NT + N + 2) + k] = w;
+            if (lane == 0) r[wave * kRedStride + k] = w;
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < CNT; ++k) {
-            double acc = red[k];
+            double acc = r[k];
 #pragma unroll
-            for (int w = 1; w < W; ++w) acc += red[w * (NT + N + 2) + k];
+            for (int w = 1; w < W; ++w) acc += r[w * kRedStride + k];
             vals[k] = acc;
         }
         __syncthreads();
     }
-
-    __device__ __forceinline__ double weight(int l) const { return sg ? 1.0 / sg[l] : 1.0; }
-
-    // residuals f = w*(model - y) into out; returns cost = 0.5 f.f ; finite=false when any f is not finite
-    __device__ double eval_f(const double *x, double *out, bool &finite) const
-    {
-        double acc = 0.0, bad = 0.0;
-        for (int l = tid; l < L; l += NTH) {
-            double e[K > 0 ? K : 1];
-            M::exps(x, t[l], e);
-            double f;
-            {
-#pragma clang fp contract(off)
-                f = weight(l) * (M::value(x, e) - y[l]);
-            }
-            out[l] = f;
-            if (!isfinite(f)) bad = 1.0; else acc += f * f;
-        }
-        double v[2] = {acc, bad};
-        block_sums<2>(v);
-        finite = v[1] == 0.0;
-        return 0.5 * v[0];
-    }
-
-    // J^T J (packed) and J^T f for the residual vector f0 stored in fbuf
-    __device__ void eval_jac(const double *x, const double *lb, const double *ub, const double *fbuf, int mode,
-                             double *A, double *g) const
-    {
-        double h[N], dx[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            // _numdiff.py:_compute_absolute_step + _adjust_scheme_to_bounds('1-sided', num_steps=1)
-            const double sgn = x[i] >= 0 ? 1.0 : -1.0;
-            double hi = 1.4901161193847656e-08 * sgn * fmax(1.0, fabs(x[i]));
-            const double ld = x[i] - lb[i], ud = ub[i] - x[i];
-            const double xp = x[i] + hi;
-            const bool violated = (xp < lb[i]) || (xp > ub[i]);
-            const bool fitting = fabs(hi) <= fmax(ld, ud);
-            if (violated && fitting) hi = -hi;
-            if (!fitting) hi = (ud >= ld) ? ud : -ld;
-            h[i] = hi;
-            dx[i] = (x[i] + hi) - x[i];
-        }
-        double Aacc[NT], gacc[N];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) Aacc[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < N; ++i) gacc[i] = 0.0;
-        for (int l = tid; l < L; l += NTH) {
-            const double tl = t[l], w = weight(l), f0 = fbuf[l];
-            double e[K > 0 ? K : 1], Jr[N];
-            M::exps(x, tl, e);
-            if (mode == 0) {
-                const double yl = y[l];
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    // model at x + h_i e_i, recomputed the way fun(x + h) evaluates it
-                    double xi[N], ei[K > 0 ? K : 1];
-#pragma unroll
-                    for (int j = 0; j < N; ++j) xi[j] = x[j];
-                    xi[i] = x[i] + h[i];
-#pragma unroll
-                    for (int k = 0; k < K; ++k) ei[k] = e[k];
-                    if (i >= K && i < 2 * K) {
-#pragma clang fp contract(off)
-                        ei[i - K] = exp((-1.0 * tl) / xi[i]);
-                    }
-                    double fi;
-                    {
-#pragma clang fp contract(off)
-                        fi = w * (M::value(xi, ei) - yl);
-                        Jr[i] = (fi - f0) / dx[i];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    Jr[k] = w * (e[k] - (M::kFreeS2 ? 0.0 : 1.0));
-                    Jr[K + k] = w * (x[k] * e[k] * tl / (x[K + k] * x[K + k]));
-                }
-                if (M::kFreeS2) Jr[N - 1] = w;
-            }
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                gacc[i] += Jr[i] * f0;
-#pragma unroll
-                for (int j = 0; j <= i; ++j) Aacc[tri(i, j)] += Jr[i] * Jr[j];
-            }
-        }
-        double all[NT + N];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) all[i] = Aacc[i];
-#pragma unroll
-        for (int i = 0; i < N; ++i) all[NT + i] = gacc[i];
-        block_sums<NT + N>(all);
-#pragma unroll
-        for (int i = 0; i < NT; ++i) A[i] = all[i];
-#pragma unroll
-        for (int i = 0; i < N; ++i) g[i] = all[NT + i];
-    }
 };
 
-template <int N, int W>
-__global__ __launch_bounds__(W * 64) void k_trf(FitArgs a)
+// cost = 0.5 f.f of the residuals f = w*(model - y); finite=false when any f is not finite
+template <int N, class R>
+__device__ __forceinline__ double eval_f(const R &T, const double *x, bool &finite)
+{
+    constexpr int K = N / 2;
+    using M = Model<N>;
+    const int tid = T.tid, L = T.L;
+    constexpr int NTH = R::NTH;
+    double acc = 0.0, bad = 0.0;
+    for (int l = tid; l < L; l += NTH) {
+        double e[K > 0 ? K : 1];
+        M::exps(x, T.ld_t(l), e);
+        double f;
+        {
+#pragma clang fp contract(off)
+            f = T.ld_w(l) * (M::value(x, e) - T.ld_y(l));
+        }
+        if (!isfinite(f)) bad = 1.0; else acc += f * f;
+    }
+    double v[2] = {acc, bad};
+    T.template block_sums<2>(v);
+    finite = v[1] == 0.0;
+    return 0.5 * v[0];
+}
+
+// J^T J (packed) and J^T f at x (f is recomputed from the same expression eval_f uses: identical bits)
+template <int N, class R>
+__device__ __forceinline__ void eval_jac(const R &T, const double *x, const double *lb, const double *ub, int mode, double *A,
+                                         double *g)
 {
     constexpr int K = N / 2;
     constexpr int NT = N * (N + 1) / 2;
-    __shared__ double red_lds[W * (NT + N + 2)];
-    const int res = blockIdx.x;
-    if (a.skip && a.skip[res]) return;
-    const int tid = threadIdx.x;
-    Trf<N, W> T;
-    T.L = a.L;
-    T.tid = tid;
-    T.red = red_lds;
-    T.t = a.t + (int64_t)res * a.L;
-    T.y = a.y + (int64_t)res * a.L;
-    T.sg = a.sigma ? a.sigma + (int64_t)res * a.L : nullptr;
-    double *fcur = a.fws + (int64_t)res * 2 * a.L, *fnew = fcur + a.L;
-    const int m = a.L;
+    using M = Model<N>;
+    const int tid = T.tid, L = T.L;
+    constexpr int NTH = R::NTH;
+    double h[N], dx[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        // _numdiff.py:_compute_absolute_step + _adjust_scheme_to_bounds('1-sided', num_steps=1)
+        const double sgn = x[i] >= 0 ? 1.0 : -1.0;
+        double hi = 1.4901161193847656e-08 * sgn * fmax(1.0, fabs(x[i]));
+        const double ld = x[i] - lb[i], ud = ub[i] - x[i];
+        const double xp = x[i] + hi;
+        const bool violated = (xp < lb[i]) || (xp > ub[i]);
+        const bool fitting = fabs(hi) <= fmax(ld, ud);
+        if (violated && fitting) hi = -hi;
+        if (!fitting) hi = (ud >= ld) ? ud : -ld;
+        h[i] = hi;
+        dx[i] = (x[i] + hi) - x[i];
+    }
+    double Aacc[NT], gacc[N];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) Aacc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) gacc[i] = 0.0;
+    for (int l = tid; l < L; l += NTH) {
+        const double tl = T.ld_t(l), w = T.ld_w(l), yl = T.ld_y(l);
+        double e[K > 0 ? K : 1], Jr[N], f0;
+        M::exps(x, tl, e);
+        {
+#pragma clang fp contract(off)
+            f0 = w * (M::value(x, e) - yl);
+        }
+        if (mode == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                // model at x + h_i e_i, recomputed the way fun(x + h) evaluates it
+                double xi[N], ei[K > 0 ? K : 1];
+#pragma unroll
+                for (int j = 0; j < N; ++j) xi[j] = x[j];
+                xi[i] = x[i] + h[i];
+#pragma unroll
+                for (int k = 0; k < K; ++k) ei[k] = e[k];
+                if (i >= K && i < 2 * K) {
+#pragma clang fp contract(off)
+                    ei[i - K] = exp((-1.0 * tl) / xi[i]);
+                }
+                double fi;
+                {
+#pragma clang fp contract(off)
+                    fi = w * (M::value(xi, ei) - yl);
+                    Jr[i] = (fi - f0) / dx[i];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                Jr[k] = w * (e[k] - (M::kFreeS2 ? 0.0 : 1.0));
+                Jr[K + k] = w * (x[k] * e[k] * tl / (x[K + k] * x[K + k]));
+            }
+            if (M::kFreeS2) Jr[N - 1] = w;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            gacc[i] += Jr[i] * f0;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Aacc[tri(i, j)] += Jr[i] * Jr[j];
+        }
+    }
+    double all[NT + N];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) all[i] = Aacc[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) all[NT + i] = gacc[i];
+    T.template block_sums<NT + N>(all);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) A[i] = all[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) g[i] = all[NT + i];
+}
 
-    double x[N], lb[N], ub[N];
+struct SolveParams {
+    double tau_max, ftol, xtol, gtol;
+    int max_nfev, jac_mode;
+};
+
+// curve_fit(...) of conduct_curve_fitting for the staged residue T, starting from p0 (registers).
+// Outputs: x (optimum), pc (packed covariance, valid when cov_ok), chi (calc_chiSq), status, nfev.
+template <int N, class R>
+__device__ __forceinline__ void trf_solve(const R &T, const double *p0, const SolveParams &P, double *x, double *pc,
+                                          bool &cov_ok, double &chi, int &status, int &nfev)
+{
+    constexpr int K = N / 2;
+    constexpr int NT = N * (N + 1) / 2;
+    const int m = T.L;
+    double lb[N], ub[N];
     bool inb = true;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        x[i] = a.p0[(int64_t)res * N + i];
+        x[i] = p0[i];
         lb[i] = 0.0;
-        ub[i] = (i >= K && i < 2 * K) ? a.tau_max : 1.0;
+        ub[i] = (i >= K && i < 2 * K) ? P.tau_max : 1.0;
         inb = inb && (x[i] >= lb[i]) && (x[i] <= ub[i]);
     }
-    int status = -99, nfev = 0;
+    status = -99;
+    nfev = 0;
     double cost = INFINITY;
     double A[NT], g[N];
 #pragma unroll
@@ -569,14 +606,14 @@ __global__ __launch_bounds__(W * 64) void k_trf(FitArgs a)
     } else {
         strictly_feasible<N>(x, lb, ub, 1e-10);
         bool finite;
-        cost = T.eval_f(x, fcur, finite);
+        cost = eval_f<N>(T, x, finite);
         nfev = 1;
         if (!finite) {
             status = -3;          // "Residuals are not finite in the initial point"
         } else {
             have_fit = true;
-            T.eval_jac(x, lb, ub, fcur, a.jac_mode, A, g);
-            const int max_nfev = a.max_nfev > 0 ? a.max_nfev : 100 * N;
+            eval_jac<N>(T, x, lb, ub, P.jac_mode, A, g);
+            const int max_nfev = P.max_nfev > 0 ? P.max_nfev : 100 * N;
             double v[N], dv[N];
             // CL_scaling_vector
 #pragma unroll
@@ -606,7 +643,7 @@ __global__ __launch_bounds__(W * 64) void k_trf(FitArgs a)
                 double g_norm = 0.0;
 #pragma unroll
                 for (int i = 0; i < N; ++i) g_norm = fmax(g_norm, fabs(g[i] * v[i]));
-                if (g_norm < a.gtol) { term = 1; term_set = true; }
+                if (g_norm < P.gtol) { term = 1; term_set = true; }
                 if (term_set || nfev == max_nfev) break;
 
                 double d[N], g_h[N], B[NT];
@@ -631,7 +668,7 @@ __global__ __launch_bounds__(W * 64) void k_trf(FitArgs a)
                     for (int i = 0; i < N; ++i) xn[i] = x[i] + step[i];
                     strictly_feasible<N>(xn, lb, ub, 0.0);
                     bool finite2;
-                    cost_new = T.eval_f(xn, fnew, finite2);
+                    cost_new = eval_f<N>(T, xn, finite2);
                     nfev += 1;
                     const double step_h_norm = normN<N>(step_h);
                     if (!finite2) {
@@ -649,8 +686,8 @@ __global__ __launch_bounds__(W * 64) void k_trf(FitArgs a)
                     else if (ratio > 0.75 && step_h_norm > 0.95 * Delta) Delta_new = Delta * 2.0;
                     const double step_norm = normN<N>(step);
                     // check_termination
-                    const bool ft = (actual_reduction < a.ftol * cost) && (ratio > 0.25);
-                    const bool xt = step_norm < a.xtol * (a.xtol + normN<N>(x));
+                    const bool ft = (actual_reduction < P.ftol * cost) && (ratio > 0.25);
+                    const bool xt = step_norm < P.xtol * (P.xtol + normN<N>(x));
                     if (ft && xt) { term = 4; term_set = true; }
                     else if (ft) { term = 2; term_set = true; }
                     else if (xt) { term = 3; term_set = true; }
@@ -661,9 +698,8 @@ __global__ __launch_bounds__(W * 64) void k_trf(FitArgs a)
                 if (actual_reduction > 0) {
 #pragma unroll
                     for (int i = 0; i < N; ++i) x[i] = xn[i];
-                    double *tmp = fcur; fcur = fnew; fnew = tmp;
                     cost = cost_new;
-                    T.eval_jac(x, lb, ub, fcur, a.jac_mode, A, g);
+                    eval_jac<N>(T, x, lb, ub, P.jac_mode, A, g);
                 }
             }
             status = term_set ? term : 0;
@@ -671,8 +707,7 @@ __global__ __launch_bounds__(W * 64) void k_trf(FitArgs a)
     }
 
     // ---- outputs: popt, pcov = (J^T J)^-1 * 2 cost / (m - n)  (curve_fit, _minpack_py.py:1040-1055), chi ----
-    double pc[NT];
-    bool cov_ok = false;
+    cov_ok = false;
     if (have_fit && m > N) {
         double Lf[NT], inv[N], lmin2;
         cov_ok = cholN<N>(A, 0.0, Lf, inv, lmin2);
@@ -698,19 +733,41 @@ __global__ __launch_bounds__(W * 64) void k_trf(FitArgs a)
             }
         }
     }
-    double chi = INFINITY;
+    chi = INFINITY;
     if (have_fit) {
         // calc_chiSq, fitting_Ct_functions.py:272-276: mean((model - y)^2 / sigma)
         double acc[1] = {0.0};
-        for (int l = tid; l < a.L; l += W * 64) {
+        for (int l = T.tid; l < T.L; l += R::NTH) {
             double e[K > 0 ? K : 1];
-            Model<N>::exps(x, T.t[l], e);
-            const double r = Model<N>::value(x, e) - T.y[l];
+            Model<N>::exps(x, T.ld_t(l), e);
+            const double r = Model<N>::value(x, e) - T.ld_y(l);
             acc[0] += T.sg ? (r * r) / T.sg[l] : r * r;
         }
         T.template block_sums<1>(acc);
-        chi = acc[0] / (double)a.L;
+        chi = acc[0] / (double)T.L;
     }
+}
+
+template <int N, int W, bool LDS>
+__global__ __launch_bounds__(W * 64) void k_trf(FitArgs a)
+{
+    constexpr int NT = N * (N + 1) / 2;
+    const int res = blockIdx.x;
+    if (a.skip && a.skip[res]) return;
+    const int tid = threadIdx.x;
+    Residue<W, LDS> T;
+    T.L = a.L;
+    T.tid = tid;
+    const double *sg_res = a.sigma ? a.sigma + (int64_t)res * a.L : nullptr;
+    T.stage(a.t + (int64_t)res * a.L, a.y + (int64_t)res * a.L, sg_res, LDS ? nullptr : a.fws + (int64_t)res * a.L);
+    double p0[N], x[N], pc[NT], chi;
+    bool cov_ok;
+    int status, nfev;
+#pragma unroll
+    for (int i = 0; i < N; ++i) p0[i] = a.p0[(int64_t)res * N + i];
+    SolveParams P;
+    P.tau_max = a.tau_max; P.ftol = a.ftol; P.xtol = a.xtol; P.gtol = a.gtol; P.max_nfev = a.max_nfev; P.jac_mode = a.jac_mode;
+    trf_solve<N>(T, p0, P, x, pc, cov_ok, chi, status, nfev);
     if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < N; ++i) a.popt[(int64_t)res * N + i] = x[i];
@@ -723,6 +780,245 @@ __global__ __launch_bounds__(W * 64) void k_trf(FitArgs a)
         a.status[res] = status;
         a.nfev[res] = nfev;
     }
+}
+
+// ---- model-order search on the device -----------------------------------------------------------------
+// optimised_curve_fitting (fitting_Ct_functions.py:278-304) with conduct_curve_fitting(bReInitialise=True)
+// (:306-345) and initialise_for_fit_advanced (:359-374) for ONE residue per workgroup, every model order in one
+// launch: initial guess -> bounded fit -> quality flags -> accept / reject -> next order.  The host used to sit in
+// this loop (one launch, six copies and ~0.6 ms of numpy per order); the only thing it still supplies is the
+// log-spaced tau guesses (numpy.logspace involves pow(), whose last bit the device cannot promise to reproduce).
+constexpr int kMaxOrders = 8;
+
+struct SearchArgs {
+    const double *t, *y, *sigma;      // (nRes, L); sigma may be null
+    int nRes, L, nOrders;
+    int orders[kMaxOrders];           // numbers of parameters, in the order they are tried
+    int tau_off[kMaxOrders];          // offset of each order's tau guesses inside a tau_guess row
+    const double *tau_guess;          // (1 or nRes, sum of orders/2)
+    int64_t tau_stride;               // 0: one row shared by every residue
+    double tau_max, chi_thr, ftol, xtol, gtol;
+    int Pmax, Kmax;
+    double *popt, *dP, *chisq;        // (nOrders, nRes, Pmax), same, (nOrders, nRes)
+    int *status, *nfev;               // (nOrders, nRes); status -100 = order not attempted
+    int *best;                        // (nRes) index into orders of the selected model, -1 = none satisfactory
+    double *sel_S2, *sel_C, *sel_tau, *sel_chi;   // (nRes), (nRes,Kmax), (nRes,Kmax), (nRes): components sorted by tau
+    int *sel_K;                       // (nRes) number of components of the selected model (0 = none)
+    double *fws;                      // (nRes, L) weights when a residue does not fit into LDS
+};
+
+// numpy.mean of n <= 128 contiguous float64 values (pairwise summation of numpy/_core/src/umath/loops_utils.h.src)
+template <class R>
+__device__ __forceinline__ double np_mean_y(const R &T, int start, int n)
+{
+#pragma clang fp contract(off)
+    double res;
+    if (n < 8) {
+        res = 0.0;
+        for (int i = 0; i < n; ++i) res += T.ld_y(start + i);
+    } else {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = T.ld_y(start + j);
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] += T.ld_y(start + i + j);
+        }
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += T.ld_y(start + i);
+    }
+    return res / (double)n;
+}
+
+struct SearchState {
+    bool first, done;
+    int best;
+    double best_chi;
+    double xbest[kNmax];
+};
+
+// Not inlined on purpose: one register allocation per model order (inlining the eight solvers into the kernel body
+// made the allocator spill 1.1 KB per lane); the residue descriptor travels by value in registers, the small
+// search state lives on the stack and is only touched before and after a solve.
+template <int N, class R>
+__device__ __noinline__ void search_order(const R T, const SearchArgs &a, int j, int res, double avgBeg, double avgEnd,
+                                          SearchState &st)
+{
+    constexpr int K = N / 2;
+    constexpr bool kFree = (N % 2) == 1;
+    constexpr int NT = N * (N + 1) / 2;
+    double p0[N], c0, sumC, S2_0;
+    {
+#pragma clang fp contract(off)
+        // initialise_for_fit_advanced, fitting_Ct_functions.py:359-374
+        c0 = fabs(avgBeg - avgEnd) / (double)K;
+        sumC = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) sumC += c0;
+        S2_0 = kFree ? avgEnd : 1.0 - sumC / (double)K;
+    }
+    const double *tg = a.tau_guess + a.tau_stride * res + a.tau_off[j];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { p0[k] = c0; p0[K + k] = tg[k]; }
+    if (kFree) p0[N - 1] = S2_0;
+
+    SolveParams P;
+    P.tau_max = a.tau_max; P.ftol = a.ftol; P.xtol = a.xtol; P.gtol = a.gtol; P.max_nfev = 100 * N; P.jac_mode = 0;
+    double x[N], pc[NT], chi;
+    bool cov_ok;
+    int status, nfev;
+    trf_solve<N>(T, p0, P, x, pc, cov_ok, chi, status, nfev);
+
+    // quality flags, fitting_Ct_functions.py:320-338 (the sum > 1 test runs on the INITIAL guess: reference quirk)
+    const bool ok = status > 0;
+    bool q1 = true;
+    double dP[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        dP[i] = cov_ok ? sqrt(pc[tri(i, i)]) : INFINITY;
+        if (dP[i] > x[i]) q1 = false;
+    }
+    bool q2;
+    {
+#pragma clang fp contract(off)
+        const double S2chk = kFree ? S2_0 : 1.0 - sumC;
+        q2 = !(S2chk + sumC > 1.0);
+    }
+    const bool allq = ok && q1 && q2;
+    const double chiSq = ok ? chi : INFINITY;
+    if (T.tid == 0) {
+        const int64_t o = (int64_t)j * a.nRes + res;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            a.popt[o * a.Pmax + i] = x[i];
+            a.dP[o * a.Pmax + i] = dP[i];
+        }
+        a.chisq[o] = chiSq;
+        a.status[o] = status;
+        a.nfev[o] = nfev;
+    }
+    // accept / reject, optimised_curve_fitting :278-304
+    bool take = false;
+    if (st.first) {
+        if (allq) { take = true; st.first = false; }
+    } else {
+        if (!allq || chiSq >= st.best_chi * a.chi_thr) st.done = true;
+        else take = true;
+    }
+    if (take) {
+        st.best = j;
+        st.best_chi = chiSq;
+#pragma unroll
+        for (int i = 0; i < N; ++i) st.xbest[i] = x[i];
+    }
+}
+
+template <int NMAX, int W, bool LDS>
+__global__ __launch_bounds__(W * 64) void k_order_search(SearchArgs a)
+{
+    const int res = blockIdx.x;
+    const int tid = threadIdx.x;
+    Residue<W, LDS> T;
+    T.L = a.L;
+    T.tid = tid;
+    const double *sg_res = a.sigma ? a.sigma + (int64_t)res * a.L : nullptr;
+    T.stage(a.t + (int64_t)res * a.L, a.y + (int64_t)res * a.L, sg_res, LDS ? nullptr : a.fws + (int64_t)res * a.L);
+
+    const int ns = a.L < 10 ? a.L : 10;                 // nSample = 10, fitting_Ct_functions.py:359
+    const double avgBeg = np_mean_y(T, 0, ns);
+    const double avgEnd = np_mean_y(T, a.L - ns, ns);
+
+    if (tid == 0) {
+        for (int j = 0; j < a.nOrders; ++j) {
+            const int64_t o = (int64_t)j * a.nRes + res;
+            for (int i = 0; i < a.Pmax; ++i) { a.popt[o * a.Pmax + i] = NAN; a.dP[o * a.Pmax + i] = NAN; }
+            a.chisq[o] = INFINITY;
+            a.status[o] = -100;
+            a.nfev[o] = 0;
+        }
+    }
+    SearchState st;
+    st.first = true; st.done = false; st.best = -1; st.best_chi = INFINITY;
+#pragma unroll
+    for (int i = 0; i < kNmax; ++i) st.xbest[i] = 0.0;
+
+    for (int j = 0; j < a.nOrders && !st.done; ++j) {
+        switch (a.orders[j]) {
+            case 2: search_order<2>(T, a, j, res, avgBeg, avgEnd, st); break;
+            case 3: search_order<3>(T, a, j, res, avgBeg, avgEnd, st); break;
+            case 4: search_order<4>(T, a, j, res, avgBeg, avgEnd, st); break;
+            case 5: search_order<5>(T, a, j, res, avgBeg, avgEnd, st); break;
+            case 6: if (NMAX >= 6) search_order<(NMAX >= 6 ? 6 : 2)>(T, a, j, res, avgBeg, avgEnd, st); break;
+            case 7: if (NMAX >= 7) search_order<(NMAX >= 7 ? 7 : 2)>(T, a, j, res, avgBeg, avgEnd, st); break;
+            case 8: if (NMAX >= 8) search_order<(NMAX >= 8 ? 8 : 2)>(T, a, j, res, avgBeg, avgEnd, st); break;
+            case 9: if (NMAX >= 9) search_order<(NMAX >= 9 ? 9 : 2)>(T, a, j, res, avgBeg, avgEnd, st); break;
+            case 10: if (NMAX >= 10) search_order<(NMAX >= 10 ? 10 : 2)>(T, a, j, res, avgBeg, avgEnd, st); break;
+            case 11: if (NMAX >= 11) search_order<(NMAX >= 11 ? 11 : 2)>(T, a, j, res, avgBeg, avgEnd, st); break;
+            default: break;
+        }
+    }
+
+    // selected model with its components sorted by tau (sort_components, fitting_Ct_functions.py:203-209)
+    if (tid == 0) {
+        a.best[res] = st.best;
+        double Cs[kNmax / 2], ts[kNmax / 2];
+        int K = 0;
+        double S2 = 0.0, chi = NAN;
+        if (st.best >= 0) {
+#pragma clang fp contract(off)
+            const int nP = a.orders[st.best];
+            K = nP / 2;
+            double sum = 0.0;
+            for (int k = 0; k < kNmax / 2; ++k) {
+                // st.xbest is indexed with compile-time constants only (registers): unrolled selects
+                double c = 0.0, tt = 0.0;
+#pragma unroll
+                for (int i = 0; i < kNmax; ++i) {
+                    if (i == k) c = st.xbest[i];
+                    if (i == K + k) tt = st.xbest[i];
+                }
+                if (k < K) { Cs[k] = c; ts[k] = tt; sum += c; }
+            }
+            double last = 0.0;
+#pragma unroll
+            for (int i = 0; i < kNmax; ++i)
+                if (i == nP - 1) last = st.xbest[i];
+            S2 = (nP & 1) ? last : 1.0 - sum;
+            chi = st.best_chi;
+            for (int i = 1; i < K; ++i) {               // stable insertion sort by tau
+                const double tc = ts[i], cc = Cs[i];
+                int q = i - 1;
+                while (q >= 0 && ts[q] > tc) { ts[q + 1] = ts[q]; Cs[q + 1] = Cs[q]; --q; }
+                ts[q + 1] = tc; Cs[q + 1] = cc;
+            }
+        }
+        a.sel_S2[res] = S2;
+        a.sel_chi[res] = chi;
+        a.sel_K[res] = K;
+        for (int k = 0; k < a.Kmax; ++k) {
+            a.sel_C[(int64_t)res * a.Kmax + k] = k < K ? Cs[k] : 0.0;
+            a.sel_tau[(int64_t)res * a.Kmax + k] = k < K ? ts[k] : 1.0;
+        }
+    }
+}
+
+template <int NMAX>
+int launch_search(sr_ctx *ctx, const SearchArgs &a)
+{
+    constexpr int W = 4;
+    const size_t lds_small = (size_t)W * kRedStride * sizeof(double);
+    const size_t lds_full = lds_small + (size_t)3 * a.L * sizeof(double);
+    if (lds_full <= sr_lds_limit(ctx)) {
+        if (lds_full > 64 * 1024)
+            SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_order_search<NMAX, W, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
+        hipLaunchKernelGGL((k_order_search<NMAX, W, true>), dim3((unsigned)a.nRes), dim3(W * 64), lds_full, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL((k_order_search<NMAX, W, false>), dim3((unsigned)a.nRes), dim3(W * 64), lds_small, ctx->stream, a);
+    }
+    SR_HIP(hipGetLastError());
+    return 0;
 }
 
 // residual + analytic Jacobian for arbitrary parameter sets
@@ -765,7 +1061,17 @@ int launch_trf(sr_ctx *ctx, const FitArgs &a)
     // 4 waves = one per SIMD of a CU: the redundant serial algebra is VALU-issue bound, a second wave per
     // SIMD doubles its time (measured at n = 9: 68 / 41 / 28 / 51 us per iteration for W = 1 / 2 / 4 / 8)
     constexpr int W = 4;
-    hipLaunchKernelGGL((k_trf<N, W>), dim3((unsigned)a.nRes), dim3(W * 64), 0, ctx->stream, a);
+    constexpr int RED = W * kRedStride;
+    const size_t lds_small = (size_t)RED * sizeof(double);
+    const size_t lds_full = lds_small + (size_t)3 * a.L * sizeof(double);
+    if (lds_full <= sr_lds_limit(ctx)) {
+        if (lds_full > 64 * 1024)
+            SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trf<N, W, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
+        hipLaunchKernelGGL((k_trf<N, W, true>), dim3((unsigned)a.nRes), dim3(W * 64), lds_full, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL((k_trf<N, W, false>), dim3((unsigned)a.nRes), dim3(W * 64), lds_small, ctx->stream, a);
+    }
     SR_HIP(hipGetLastError());
     return 0;
 }
@@ -809,6 +1115,96 @@ int sr_expfit_lm_f64_dev(sr_ctx *ctx, const double *t, const double *C, const do
     a.popt = popt; a.pcov = pcov; a.chisq = chisq; a.status = status; a.nfev = n_iter; a.fws = fws;
     if (max_iter < 0) { a.max_nfev = -max_iter; a.jac_mode = 1; }     // negative: analytic Jacobian variant
     return dispatch_trf(ctx, P, a);
+}
+
+int sr_expfit_order_search_f64_dev(sr_ctx *ctx, const double *t, const double *C, const double *sigma, int nRes, int L,
+                                   const int *orders, int nOrders, const double *tau_guess, int tau_guess_rows,
+                                   double tau_max, double chi_threshold, double *work, double *popt, double *dP,
+                                   double *chisq, int *status, int *nfev, int *best, double *sel_S2, double *sel_C,
+                                   double *sel_tau, double *sel_chi, int *sel_K)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(t && C && orders && tau_guess && popt && dP && chisq && status && nfev && best && sel_S2 && sel_C && sel_tau &&
+                   sel_chi && sel_K, -2, "sr_expfit_order_search_f64_dev: null pointer");
+    SR_REQUIRE(nRes >= 1 && L >= 1 && nOrders >= 1 && nOrders <= kMaxOrders, -3,
+               "sr_expfit_order_search_f64_dev: bad sizes nRes=%d L=%d nOrders=%d (at most %d orders)", nRes, L, nOrders, kMaxOrders);
+    SR_REQUIRE(tau_guess_rows == 1 || tau_guess_rows == nRes, -3, "sr_expfit_order_search_f64_dev: tau_guess_rows must be 1 or nRes");
+    SearchArgs a;
+    int pmax = 0, off = 0;
+    for (int j = 0; j < nOrders; ++j) {
+        SR_REQUIRE(orders[j] >= 2 && orders[j] <= kNmax, -3, "sr_expfit_order_search_f64_dev: order %d not supported (2..%d)",
+                   orders[j], kNmax);
+        a.orders[j] = orders[j];
+        a.tau_off[j] = off;
+        off += orders[j] / 2;
+        pmax = orders[j] > pmax ? orders[j] : pmax;
+    }
+    for (int j = nOrders; j < kMaxOrders; ++j) { a.orders[j] = 0; a.tau_off[j] = 0; }
+    const size_t lds_full = ((size_t)4 * kRedStride + (size_t)3 * L) * sizeof(double);
+    double *fws = work;
+    if (!fws && lds_full > sr_lds_limit(ctx)) {
+        fws = (double *)sr_workspace(ctx, SR_WS_FIT, (size_t)nRes * L * sizeof(double));
+        if (!fws) return -5;
+    }
+    a.t = t; a.y = C; a.sigma = sigma; a.nRes = nRes; a.L = L; a.nOrders = nOrders;
+    a.tau_guess = tau_guess; a.tau_stride = tau_guess_rows == 1 ? 0 : off;
+    a.tau_max = tau_max; a.chi_thr = chi_threshold; a.ftol = a.xtol = a.gtol = 1e-8;
+    a.Pmax = pmax; a.Kmax = pmax / 2;
+    a.popt = popt; a.dP = dP; a.chisq = chisq; a.status = status; a.nfev = nfev; a.best = best;
+    a.sel_S2 = sel_S2; a.sel_C = sel_C; a.sel_tau = sel_tau; a.sel_chi = sel_chi; a.sel_K = sel_K; a.fws = fws;
+    if (pmax <= 5) return launch_search<5>(ctx, a);
+    if (pmax <= 9) return launch_search<9>(ctx, a);
+    return launch_search<11>(ctx, a);
+}
+
+int sr_expfit_order_search_f64(sr_ctx *ctx, const double *t, const double *C, const double *sigma, int nRes, int L,
+                               const int *orders, int nOrders, const double *tau_guess, int tau_guess_rows, double tau_max,
+                               double chi_threshold, double *popt, double *dP, double *chisq, int *status, int *nfev,
+                               int *best, double *sel_S2, double *sel_C, double *sel_tau, double *sel_chi, int *sel_K)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(t && C && orders && tau_guess && popt && dP && chisq && status && nfev && best && sel_S2 && sel_C && sel_tau &&
+                   sel_chi && sel_K, -2, "sr_expfit_order_search_f64: null pointer");
+    SR_REQUIRE(nRes >= 1 && L >= 1 && nOrders >= 1 && nOrders <= kMaxOrders, -3, "sr_expfit_order_search_f64: bad sizes");
+    SR_REQUIRE(tau_guess_rows == 1 || tau_guess_rows == nRes, -3, "sr_expfit_order_search_f64: tau_guess_rows must be 1 or nRes");
+    int pmax = 0, sumK = 0;
+    for (int j = 0; j < nOrders; ++j) {
+        SR_REQUIRE(orders[j] >= 2 && orders[j] <= kNmax, -3, "sr_expfit_order_search_f64: order %d not supported", orders[j]);
+        pmax = orders[j] > pmax ? orders[j] : pmax;
+        sumK += orders[j] / 2;
+    }
+    const size_t nL = (size_t)nRes * L, nR = (size_t)nRes, nO = (size_t)nOrders, kmax = (size_t)(pmax / 2);
+    const size_t ntau = (size_t)tau_guess_rows * sumK;
+    double *in = (double *)sr_workspace(ctx, SR_WS_IN0, (3 * nL + ntau) * sizeof(double));
+    const size_t nd = 2 * nO * nR * pmax + nO * nR + nR * (2 + 2 * kmax);
+    double *out = (double *)sr_workspace(ctx, SR_WS_OUT0, nd * sizeof(double));
+    int *iout = (int *)sr_workspace(ctx, SR_WS_OUT1, (2 * nO * nR + 2 * nR) * sizeof(int));
+    if (!in || !out || !iout) return -5;
+    double *t_d = in, *y_d = in + nL, *s_d = in + 2 * nL, *tg_d = in + 3 * nL;
+    SR_HIP(hipMemcpyAsync(t_d, t, nL * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SR_HIP(hipMemcpyAsync(y_d, C, nL * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (sigma) SR_HIP(hipMemcpyAsync(s_d, sigma, nL * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SR_HIP(hipMemcpyAsync(tg_d, tau_guess, ntau * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    double *popt_d = out, *dP_d = popt_d + nO * nR * pmax, *chi_d = dP_d + nO * nR * pmax, *sS2_d = chi_d + nO * nR;
+    double *sC_d = sS2_d + nR, *st_d = sC_d + nR * kmax, *schi_d = st_d + nR * kmax;
+    int *status_d = iout, *nfev_d = iout + nO * nR, *best_d = nfev_d + nO * nR, *sK_d = best_d + nR;
+    int rc = sr_expfit_order_search_f64_dev(ctx, t_d, y_d, sigma ? s_d : nullptr, nRes, L, orders, nOrders, tg_d, tau_guess_rows,
+                                            tau_max, chi_threshold, nullptr, popt_d, dP_d, chi_d, status_d, nfev_d, best_d,
+                                            sS2_d, sC_d, st_d, schi_d, sK_d);
+    if (rc) return rc;
+    SR_HIP(hipMemcpyAsync(popt, popt_d, nO * nR * pmax * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(dP, dP_d, nO * nR * pmax * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(chisq, chi_d, nO * nR * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(sel_S2, sS2_d, nR * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(sel_C, sC_d, nR * kmax * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(sel_tau, st_d, nR * kmax * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(sel_chi, schi_d, nR * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(status, status_d, nO * nR * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(nfev, nfev_d, nO * nR * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(best, best_d, nR * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(sel_K, sK_d, nR * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 int sr_expfit_lm_f64(sr_ctx *ctx, const double *t, const double *C, const double *sigma, int nRes, int L, int P,

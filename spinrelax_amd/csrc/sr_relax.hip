@@ -27,6 +27,7 @@ constexpr int kNC = 2;       // covariances: (a1,b1), (a2,b2)
 struct RelaxArgs {
     int model, E, nRes, Kmax, B, noe_mode;
     double D0, D1;
+    double zeta;          // S2 and C are multiplied by this on load (1.0: already scaled by the caller)
     const double *omega, *f_DD, *f_CSA, *time_fact, *gamma_ratio;
     const double *S2, *C, *tau;
     const int *nComps;
@@ -77,9 +78,10 @@ __global__ __launch_bounds__(256) void k_relax(RelaxArgs a)
     const int i = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
     const double *om = a.omega + e * 5;
     const double fDD = a.f_DD[e], fCSA = a.f_CSA[(int64_t)e * a.nRes + i], tf = a.time_fact[e], gr = a.gamma_ratio[e];
-    const double S2 = a.S2[i];
+    const double S2 = a.zeta * a.S2[i];
     const double *C = a.C + (int64_t)i * a.Kmax, *tau = a.tau + (int64_t)i * a.Kmax;
     const int K = a.nComps[i];
+    const double zeta = a.zeta;
     const bool prolate = a.D0 > a.D1;
     double *out = a.out + ((int64_t)e * a.nRes + i) * 8;
     double *Jout = a.Jout ? a.Jout + ((int64_t)e * a.nRes + i) * 10 : nullptr;
@@ -92,17 +94,18 @@ __global__ __launch_bounds__(256) void k_relax(RelaxArgs a)
             const double Dpar = a.D0, Dperp = a.D1;
             const double DJ = j == 0 ? 5 * Dperp + Dpar : (j == 1 ? 2 * Dperp + 4 * Dpar : 6 * Dperp);
             g = S2 * jomega(DJ, om[w]);
-            for (int k = 0; k < K; ++k) g += C[k] * jomega(DJ + 1. / tau[k], om[w]);
+            for (int k = 0; k < K; ++k) { const double ck = zeta * C[k]; g += ck * jomega(DJ + 1. / tau[k], om[w]); }
         } else if (j == 0) {
             if (a.model == 1) {
                 const double tg = 1.0 / (6.0 * a.D0);
                 g = S2 * tg / (1. + (om[w] * tg) * (om[w] * tg));
                 for (int k = 0; k < K; ++k) {
                     const double kk = (1.0 / tg) + (1.0 / tau[k]);
-                    g += C[k] * kk / (kk * kk + om[w] * om[w]);
+                    const double ck = zeta * C[k];
+                    g += ck * kk / (kk * kk + om[w] * om[w]);
                 }
             } else {
-                for (int k = 0; k < K; ++k) g += C[k] * tau[k] / (1 + (tau[k] * om[w]) * (tau[k] * om[w]));
+                for (int k = 0; k < K; ++k) { const double ck = zeta * C[k]; g += ck * tau[k] / (1 + (tau[k] * om[w]) * (tau[k] * om[w])); }
             }
         }
         G[j][w] = g;
@@ -267,6 +270,7 @@ int sr_jomega_relax_f64(sr_ctx *ctx, int model, const double *D, int E, const do
     a.model = model; a.E = E; a.nRes = nRes; a.Kmax = Kmax; a.B = (model == 2) ? B : 0; a.noe_mode = noe_mode;
     a.D0 = D ? D[0] : 0.0;
     a.D1 = (D && model == 2) ? D[1] : 0.0;
+    a.zeta = 1.0;
     double *p = stage;
     auto put = [&](const double *src, size_t n) -> const double * {
         hipError_t e = hipMemcpyAsync(p, src, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
@@ -300,6 +304,35 @@ int sr_jomega_relax_f64(sr_ctx *ctx, int model, const double *D, int E, const do
     if (Jout) SR_HIP(hipMemcpyAsync(Jout, J_d, nE * nR * 10 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (stats) SR_HIP(hipMemcpyAsync(stats, st_d, nE * nR * 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sr_jomega_relax_f64_dev(sr_ctx *ctx, int model, const double *D, int E, const double *omega, const double *f_DD,
+                            const double *f_CSA, const double *time_fact, const double *gamma_ratio, int nRes, int Kmax,
+                            double zeta, const double *S2, const double *C, const double *tau, const int *nComps, int B,
+                            const double *binvecs, const double *weights, int noe_mode, double *out, double *Jout,
+                            double *stats)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(model >= 0 && model <= 2, -3, "sr_jomega_relax_f64_dev: model must be 0, 1 or 2");
+    SR_REQUIRE(E >= 1 && E <= 65535 && nRes >= 1 && Kmax >= 1 && Kmax <= kMaxK && B >= 0, -3, "sr_jomega_relax_f64_dev: bad sizes");
+    SR_REQUIRE(omega && f_DD && f_CSA && time_fact && gamma_ratio && S2 && C && tau && nComps && out, -2,
+               "sr_jomega_relax_f64_dev: null pointer");
+    SR_REQUIRE(model == 0 || D, -2, "sr_jomega_relax_f64_dev: D required");
+    SR_REQUIRE(model != 2 || binvecs, -2, "sr_jomega_relax_f64_dev: symmetric top needs vectors");
+    SR_REQUIRE(noe_mode == 0 || noe_mode == 1, -3, "sr_jomega_relax_f64_dev: noe_mode must be 0 or 1");
+    RelaxArgs a;
+    a.model = model; a.E = E; a.nRes = nRes; a.Kmax = Kmax; a.B = (model == 2) ? B : 0; a.noe_mode = noe_mode;
+    a.D0 = D ? D[0] : 0.0;
+    a.D1 = (D && model == 2) ? D[1] : 0.0;
+    a.zeta = zeta;
+    a.omega = omega; a.f_DD = f_DD; a.f_CSA = f_CSA; a.time_fact = time_fact; a.gamma_ratio = gamma_ratio;
+    a.S2 = S2; a.C = C; a.tau = tau; a.nComps = nComps;
+    a.binvecs = model == 2 ? binvecs : nullptr;
+    a.weights = (model == 2 && B > 0) ? weights : nullptr;
+    a.out = out; a.Jout = Jout; a.stats = stats;
+    hipLaunchKernelGGL(k_relax, dim3((unsigned)nRes, (unsigned)E), dim3(256), 0, ctx->stream, a);
+    SR_HIP(hipGetLastError());
     return 0;
 }
 

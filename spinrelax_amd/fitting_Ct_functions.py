@@ -391,6 +391,35 @@ def host_runner(t, y, dy, ctx=None):
     return run
 
 
+def tau_guesses(t, listDoG):
+    """The log-spaced tau part of initialise_for_fit_advanced (fitting_Ct_functions.py:361-362) for every order of
+    listDoG, concatenated: (1, sum K) when every residue shares its time axis, else (n, sum K).  Same numpy calls as
+    initial_guess, so the device search starts from bit-identical guesses."""
+    t = np.atleast_2d(np.asarray(t, dtype=float))
+    rows = t[:1] if (t.shape[0] == 1 or np.all(t == t[0])) else t
+    out = []
+    for ti in rows:
+        row = []
+        for nP in listDoG:
+            K = int(nP / 2)
+            row.append(np.logspace(np.log10(np.mean(ti[1:] - ti[:-1])), np.log10(ti[-1] * 2.0), K + 2)[1:-1])
+        out.append(np.concatenate(row))
+    return np.ascontiguousarray(out)
+
+
+def order_search_device(t, y, dy, listDoG=(2, 3, 5, 7, 9), chiSqThreshold=0.5, ctx=None):
+    """optimised_curve_fitting for all residues in ONE kernel launch (model orders, quality flags and the accept /
+    reject rule evaluated on the GPU).  Returns the dict of Context.order_search."""
+    t = np.atleast_2d(np.asarray(t, dtype=float))
+    y = np.atleast_2d(np.asarray(y, dtype=float))
+    if t.shape[0] == 1 and y.shape[0] > 1:
+        t = np.ascontiguousarray(np.broadcast_to(t, y.shape))
+    tau_max = t[0, -1] * 10                      # fitting_Ct_functions.py:324 (per-residue axes share their end point)
+    if not np.all(t[:, -1] == t[0, -1]):
+        raise ValueError('order_search_device: residues with different final times need separate calls (tau bound)')
+    return _ctx(ctx).order_search(t, y, dy, listDoG, tau_guesses(t, listDoG), tau_max, chiSqThreshold)
+
+
 def fit_request(t, y, nParams, active=None):
     """First half of conduct_curve_fitting(bReInitialise=True) for a batch: the residues to solve and their
     initial guesses.  Returns dict(nParams, idx, p0, C0, S2_0)."""

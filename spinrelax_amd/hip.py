@@ -57,6 +57,20 @@ class Context:
     def sync(self):
         check(self.lib.sr_sync(self.h), 'sr_sync')
 
+    def stream_create(self, cu_mask_words=None, priority=0):
+        """hipStream_t handle (int); cu_mask_words = iterable of 32-bit words, bit set = CU usable."""
+        out = ctypes.c_void_p()
+        if cu_mask_words is not None:
+            words = (ctypes.c_uint32 * len(cu_mask_words))(*[int(w) & 0xFFFFFFFF for w in cu_mask_words])
+            check(self.lib.sr_stream_create(self.h, words, len(cu_mask_words), priority, ctypes.byref(out)),
+                  'sr_stream_create')
+        else:
+            check(self.lib.sr_stream_create(self.h, None, 0, priority, ctypes.byref(out)), 'sr_stream_create')
+        return out.value
+
+    def stream_destroy(self, handle):
+        check(self.lib.sr_stream_destroy(self.h, ctypes.c_void_p(handle)), 'sr_stream_destroy')
+
     def device_info(self):
         ncu = ctypes.c_int()
         hbm = ctypes.c_int64()
@@ -183,6 +197,45 @@ class Context:
         check(self.lib.sr_expfit_lm_f64_dev(self.h, t_ptr, y_ptr, sigma_ptr, nRes, L, P, p0_ptr, float(tau_max),
                                             int(max_nfev), skip_ptr, work_ptr, popt_ptr, pcov_ptr, chisq_ptr, status_ptr, nfev_ptr),
               'sr_expfit_lm_f64_dev')
+
+    def order_search(self, t, y, sigma, orders, tau_guess, tau_max, chi_threshold=0.5):
+        """optimised_curve_fitting for (n, L) host arrays in one launch (sr_expfit_order_search_f64).  tau_guess:
+        (1 or n, sum(orders)//2... one block of order//2 guesses per order).  Returns a dict of host arrays."""
+        t, y = _f64(t), _f64(y)
+        n, L = y.shape
+        sigma = None if sigma is None else _f64(sigma)
+        orders = np.ascontiguousarray(orders, dtype=np.int32)
+        nO, Pmax = orders.size, int(orders.max())
+        Kmax = Pmax // 2
+        tg = _f64(np.atleast_2d(tau_guess))
+        out = dict(popt=np.empty((nO, n, Pmax)), dP=np.empty((nO, n, Pmax)), chisq=np.empty((nO, n)),
+                   status=np.empty((nO, n), dtype=np.int32), nfev=np.empty((nO, n), dtype=np.int32),
+                   best=np.empty(n, dtype=np.int32), S2=np.empty(n), C=np.empty((n, Kmax)), tau=np.empty((n, Kmax)),
+                   chi=np.empty(n), K=np.empty(n, dtype=np.int32))
+        check(self.lib.sr_expfit_order_search_f64(self.h, _ptr(t), _ptr(y), None if sigma is None else _ptr(sigma), n, L,
+                                                  _ptr(orders), nO, _ptr(tg), tg.shape[0], float(tau_max), float(chi_threshold),
+                                                  _ptr(out['popt']), _ptr(out['dP']), _ptr(out['chisq']), _ptr(out['status']),
+                                                  _ptr(out['nfev']), _ptr(out['best']), _ptr(out['S2']), _ptr(out['C']),
+                                                  _ptr(out['tau']), _ptr(out['chi']), _ptr(out['K'])),
+              'sr_expfit_order_search_f64')
+        out['orders'] = orders
+        return out
+
+    def order_search_dev(self, t_ptr, y_ptr, sigma_ptr, nRes, L, orders, tau_guess_ptr, tau_rows, tau_max, chi_threshold,
+                         popt_ptr, dP_ptr, chisq_ptr, status_ptr, nfev_ptr, best_ptr, S2_ptr, C_ptr, tau_ptr, chi_ptr, K_ptr,
+                         work_ptr=None):
+        orders = np.ascontiguousarray(orders, dtype=np.int32)
+        check(self.lib.sr_expfit_order_search_f64_dev(self.h, t_ptr, y_ptr, sigma_ptr, nRes, L, _ptr(orders), orders.size,
+                                                      tau_guess_ptr, tau_rows, float(tau_max), float(chi_threshold), work_ptr,
+                                                      popt_ptr, dP_ptr, chisq_ptr, status_ptr, nfev_ptr, best_ptr, S2_ptr, C_ptr,
+                                                      tau_ptr, chi_ptr, K_ptr), 'sr_expfit_order_search_f64_dev')
+
+    def relax_dev(self, model, D, E, omega_ptr, fDD_ptr, fCSA_ptr, tf_ptr, gr_ptr, nRes, Kmax, zeta, S2_ptr, C_ptr, tau_ptr,
+                  K_ptr, B, binvecs_ptr, weights_ptr, noe_mode, out_ptr, Jout_ptr=None, stats_ptr=None):
+        Dh = _f64(np.atleast_1d(D))
+        check(self.lib.sr_jomega_relax_f64_dev(self.h, model, _ptr(Dh), E, omega_ptr, fDD_ptr, fCSA_ptr, tf_ptr, gr_ptr, nRes,
+                                               Kmax, float(zeta), S2_ptr, C_ptr, tau_ptr, K_ptr, B, binvecs_ptr, weights_ptr,
+                                               noe_mode, out_ptr, Jout_ptr, stats_ptr), 'sr_jomega_relax_f64_dev')
 
     def transpose_dev(self, in_ptr, rows, cols, out_ptr):
         check(self.lib.sr_transpose_f64_dev(self.h, in_ptr, rows, cols, out_ptr), 'sr_transpose_f64_dev')

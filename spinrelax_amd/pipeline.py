@@ -67,7 +67,8 @@ class _Slot:
 
 class DevicePipeline:
     def __init__(self, ctx, device, frames, V, R, F, dt, q_rot=None, Diso=None, aniso=None, field_MHz=(600.133,),
-                 zeta=0.890023, histBinX=72, listDoG=(2, 3, 5, 7, 9), csa=None, depth=1, stream=None):
+                 zeta=0.890023, histBinX=72, listDoG=(2, 3, 5, 7, 9), csa=None, depth=1, stream=None, reserve_cus=0,
+                 fits_on_reserved_only=False):
         self.ctx = ctx
         self.dev = device
         self.frames, self.V, self.R, self.F, self.dt = frames, V, R, F, dt
@@ -83,11 +84,29 @@ class DevicePipeline:
         self.nbins = histBinX * int(histBinX / 2)
         self.depth = max(1, int(depth))
         self.main = stream if stream is not None else torch.cuda.current_stream(device)
+        self._owned_streams = []
+        resv_words = None
+        self.reserve_cus = 0
+        if reserve_cus and self.depth > 1:
+            # Chip partition.  A C(t) launch keeps every CU full for its whole duration and the workgroup dispatcher
+            # hands a freed slot to the next workgroup of the launch already in flight: fit kernels queued meanwhile
+            # (even on a high-priority queue) only start when the C(t) grid has drained (rocprofv3 kernel trace:
+            # k_trf<3> 6.6 ms queued behind C(t) against 0.39 ms alone).  So the throughput kernels run on a stream
+            # whose CU mask leaves `reserve_cus` CUs free for the fits.  Mask bit i is CU i/8 of XCD i%8 on MI355X
+            # (scripts/dev_cumask.py), so a multiple of 8 taken from the top keeps the 8 XCDs balanced.
+            ncu = ctx.device_info()['n_cu']
+            nx = 8
+            r = min(ncu - nx, (int(reserve_cus) + nx - 1) // nx * nx)
+            self.reserve_cus = r
+            self.main = self._masked_stream(range(ncu - r), ncu)
+            if fits_on_reserved_only:
+                resv_words = self._mask_words(range(ncu - r, ncu), ncu)
         # one side stream per slot so that the stragglers of consecutive batches overlap each other as well
-        # the fit kernels are short and latency-critical (the host waits on them): high-priority queues, so that their
-        # few workgroups are placed ahead of the thousands of queued C(t) workgroups of the next batch
-        self.sides = [torch.cuda.Stream(device=device, priority=-1) for _ in range(self.depth)] if self.depth > 2 else None
-        self.fitstream = torch.cuda.Stream(device=device, priority=-1) if self.depth > 1 else self.main
+        if self.depth > 2:
+            self.sides = [self._fit_stream(resv_words) for _ in range(self.depth)]
+        else:
+            self.sides = None
+        self.fitstream = self._fit_stream(resv_words) if self.depth > 1 else self.main
         self.soa = torch.empty((V, 3, self.Npad), device=device, dtype=torch.float32)
         Pmax = max(self.listDoG)
         self.slots = [_Slot(device, V, self.L, R, self.nbins, Pmax) for _ in range(self.depth)]
@@ -111,6 +130,33 @@ class DevicePipeline:
             tf.append(RObj.time_fact)
             gr.append(RObj.gH.gamma / RObj.gX.gamma)
         self._relax_consts = (np.array(oms), np.array(fdd), np.array(fcsa), np.array(tf), np.array(gr))
+
+    # ---- streams ----
+    @staticmethod
+    def _mask_words(bits, ncu):
+        w = [0] * ((ncu + 31) // 32)
+        for b in bits:
+            w[b // 32] |= 1 << (b % 32)
+        return w
+
+    def _masked_stream(self, bits, ncu):
+        h = self.ctx.stream_create(self._mask_words(bits, ncu))
+        self._owned_streams.append(h)
+        return torch.cuda.ExternalStream(h, device=self.dev)
+
+    def _fit_stream(self, resv_words):
+        if resv_words is None:
+            return torch.cuda.Stream(device=self.dev, priority=-1)
+        h = self.ctx.stream_create(resv_words)
+        self._owned_streams.append(h)
+        return torch.cuda.ExternalStream(h, device=self.dev)
+
+    def close(self):
+        torch.cuda.synchronize(self.dev)
+        self.ctx.set_stream(0)
+        for h in self._owned_streams:
+            self.ctx.stream_destroy(h)
+        self._owned_streams = []
 
     # ---- stages on the main stream ----
     def stage_pack(self, vecs):

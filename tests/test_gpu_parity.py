@@ -406,3 +406,73 @@ def test_device_fit_failure_modes(ctx):
     yy[3] = np.nan
     _, _, chi, status, _ = ctx.expfit(t, yy[None], None, [[0.2, 100.0, 0.8]], 5000.0)
     assert status[0] == -3
+
+
+def _host_driven_search(fitCt, t, y, dy, orders, ctx):
+    search = fitCt.OrderSearchBatch(t, y, orders, 0.5)
+    runner = fitCt.host_runner(t, y, dy, ctx=ctx)
+    while True:
+        req = search.request()
+        if req is None:
+            break
+        search.submit(*runner(req['nParams'], req['p0'], req['idx']))
+    return search
+
+
+@pytest.mark.parametrize('tag', ['cfg1', 'cfg2', 'cfg3s'])
+def test_device_order_search_equals_host_driven_search(ctx, tag):
+    """The one-launch model-order search (sr_expfit_order_search_f64: guesses, fits, quality flags and accept/reject
+    on the GPU) against the host-driven state machine OrderSearchBatch, which mirrors
+    optimised_curve_fitting (fitting_Ct_functions.py:278-304) and is itself checked against the reference's
+    selections in tests/test_formats_and_hostlogic.py.  Both drive the same device solver from the same initial
+    guesses, so everything must agree bit for bit: selection, parameters, chi^2, evaluation counts."""
+    from spinrelax_amd import fitting_Ct_functions as fitCt
+    g = golden('%s_fit.npz' % tag)
+    t, y, dy = g['t'], g['y'], g['dy']
+    orders = tuple(int(v) for v in g['listDoG'])
+    dev = fitCt.order_search_device(t, y, dy, orders, 0.5, ctx=ctx)
+    search = _host_driven_search(fitCt, t, y, dy, orders, ctx)
+    assert np.array_equal(dev['best'], search.best)
+    # initial guesses: the p0 the reference itself used for every trial (first K amplitudes and the taus)
+    for j, res in enumerate(search.per_order):
+        nP = res['nParams']
+        tried = dev['status'][j] != -100
+        host_tried = ~np.isnan(res['p0'][:, 0])
+        assert np.array_equal(tried, host_tried)
+        idx = np.flatnonzero(tried)
+        assert np.array_equal(dev['popt'][j][idx, :nP], res['popt'][idx])
+        assert np.array_equal(dev['dP'][j][idx, :nP], res['dP'][idx], equal_nan=True)
+        assert np.array_equal(dev['chisq'][j][idx], res['chiSq'][idx])
+    S2, C, tau, K, chi = search.selected_arrays(Kmax=max(orders) // 2)
+    assert np.array_equal(dev['K'], K)
+    assert np.array_equal(dev['S2'], S2) and np.array_equal(dev['C'], C) and np.array_equal(dev['tau'], tau)
+    assert np.array_equal(dev['chi'], chi, equal_nan=True)
+    # and the reference's own selection (number of parameters of the accepted model) where its fits are stable
+    ref_best = g['sel_nParams'] if 'sel_nParams' in g else None
+    if ref_best is not None:
+        mine = np.where(dev['best'] >= 0, np.asarray(orders)[np.maximum(dev['best'], 0)], 0)
+        agree = np.mean(mine == ref_best)
+        print('%s: selected order equals the reference for %.1f %% of the residues' % (tag, 100 * agree))
+        assert agree >= 0.9
+
+
+def test_device_order_search_edge_cases(ctx):
+    """Short series (fewer than 10 lags: the means of initialise_for_fit_advanced shrink), a residue the first order
+    already fails on (NaN), per-residue time axes, and L too long for LDS (global-memory path)."""
+    from spinrelax_amd import fitting_Ct_functions as fitCt
+    rng = np.random.default_rng(3)
+    for L in (7, 64, 9000):
+        t = np.arange(1, L + 1) * 10.0
+        n = 5
+        S2 = rng.uniform(0.3, 0.9, n)
+        y = S2[:, None] + (1 - S2[:, None]) * np.exp(-t[None, :] / rng.uniform(50, 500, n)[:, None])
+        y += 1e-4 * rng.standard_normal(y.shape)
+        y[2, min(3, L - 1)] = np.nan
+        dy = np.full_like(y, 1e-3)
+        tt = np.ascontiguousarray(np.broadcast_to(t, y.shape))
+        dev = fitCt.order_search_device(tt, y, dy, (2, 3, 5), 0.5, ctx=ctx)
+        search = _host_driven_search(fitCt, tt, y, dy, (2, 3, 5), ctx)
+        assert np.array_equal(dev['best'], search.best), L
+        assert dev['best'][2] == -1 and dev['K'][2] == 0
+        S2h, Ch, tauh, Kh, chih = search.selected_arrays(Kmax=2)
+        assert np.array_equal(dev['S2'], S2h) and np.array_equal(dev['C'], Ch) and np.array_equal(dev['tau'], tauh)

@@ -31,6 +31,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# one hardware queue per in-flight batch (their fit stragglers run ~25 ms each) + the C(t) stream; the HIP runtime
+# multiplexes streams onto 4 queues by default and streams that share a queue serialise (spinrelax_amd/pipeline.py)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector = FP32 matrix peak
 PEAK_HBM_GBS = 8000.0
@@ -43,8 +46,11 @@ def parse():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', type=str, default='cfg3', choices=['cfg2', 'cfg3'])
     ap.add_argument('--vectors', type=int, default=None, help='vectors per GPU (default: the config value)')
-    ap.add_argument('--reserve-cus', type=int, default=16, help='CUs kept free of the C(t)/histogram kernels for the latency-bound fit kernels (CU-masked stream; 0 = no partition)')
+    ap.add_argument('--reserve-cus', type=int, default=0, help='CUs kept free of the C(t)/histogram kernels for the latency-bound fit kernels (CU-masked stream; 0 = no partition)')
     ap.add_argument('--fits-on-reserved-only', action='store_true', help='confine the fit kernels to the reserved CUs')
+    ap.add_argument('--fit-waves', type=int, default=0, help='wavefronts per residue in the model-order search (0 = library default)')
+    ap.add_argument('--fit-lds', type=int, default=-1, help='1/0: keep residue data in LDS during the fits (-1 = library default)')
+    ap.add_argument('--dev-skip-fits', action='store_true', help='DEVELOPMENT ONLY (invalid as a benchmark): leave the fits and the relaxation kernel out, to see the floor the C(t) side alone sets')
     ap.add_argument('--depth', type=int, default=4, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
@@ -128,12 +134,19 @@ def main():
 
     vecs = torch.from_numpy(vecs_host).to(dev)           # resident in HBM before the timed region
     ctx = Context(local)
+    if args.fit_waves:
+        ctx.set_option('fit_waves', args.fit_waves)
+    if args.fit_lds >= 0:
+        ctx.set_option('fit_lds', args.fit_lds)
     triples = synth.exact_triples(s['R'], s['F'], V)
     pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], q_rot=q, Diso=synth.DISO, aniso=aniso,
                           field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA, depth=args.depth,
                           stream=torch.cuda.Stream(device=dev), reserve_cus=args.reserve_cus,
                           fits_on_reserved_only=args.fits_on_reserved_only)
     stream = pipe.main
+    if args.dev_skip_fits:
+        pipe.stage_fit = lambda s=None: None
+        pipe.stage_relax = lambda s=None: None
     ctx.set_stream(stream.cuda_stream)
 
     with torch.cuda.stream(stream):
@@ -168,14 +181,12 @@ def main():
 
     if args.stage_breakdown and rank == 0:
         with torch.cuda.stream(stream):
-            names = ['pack', 'ct', 'hist', 'fit', 'relax']
+            names = ['pack', 'ct', 'hist', 'transpose', 'fit', 'relax', 'download']
             s0 = pipe.slots[0]
-
-            def _fit():
-                pipe.stage_fit_begin(s0, defer_last=False)
-                pipe.stage_fit_end(s0)
-            fns = [lambda: pipe.stage_pack(vecs), lambda: pipe.stage_ct(s0), lambda: pipe.stage_hist(s0), _fit,
-                   lambda: pipe.stage_relax(s0)]
+            ctx.set_stream(stream.cuda_stream)
+            fns = [lambda: pipe.stage_pack(vecs), lambda: pipe.stage_ct(s0), lambda: pipe.stage_hist(s0),
+                   lambda: pipe.stage_transpose(s0), lambda: pipe.stage_fit(s0), lambda: pipe.stage_relax(s0),
+                   lambda: pipe.stage_download(s0)]
             acc = {n: 0.0 for n in names}
             for _ in range(3):
                 for n, fn in zip(names, fns):
@@ -220,6 +231,7 @@ def main():
             'fit': {'residues': V, 'selected_orders': {str(pipe.listDoG[j]): int((best == j).sum()) for j in range(len(pipe.listDoG))},
                     'unfitted': int((best < 0).sum())},
             'setup': {'synth_s': gen_s},
+            **({'INVALID': 'fits skipped (--dev-skip-fits)'} if args.dev_skip_fits else {}),
         }
         if world == 1 and not args.no_cpu_baseline:
             nvs = min(args.cpu_sample_vectors, V)

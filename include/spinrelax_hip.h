@@ -38,6 +38,9 @@ sr_ctx      *sr_create(int device);                 /* NULL on failure (see sr_l
 void         sr_destroy(sr_ctx *);
 int          sr_set_stream(sr_ctx *, void *hip_stream);   /* hipStream_t; NULL = default stream  */
 int          sr_sync(sr_ctx *);
+/* Tuning knobs: "fit_waves" = wavefronts per residue in the model-order search (1, 2 or 4; default 4: shortest
+ * time per residue; 1: least resources per residue), "fit_lds" = 1/0 keep a residue's t, C(t), 1/sigma in LDS. */
+int          sr_set_option(sr_ctx *, const char *name, int value);
 /* Streams that partition the chip.  The fits of fitting_Ct_functions.py:278-345 are a latency chain of small
  * launches; queued behind a C(t) launch that fills every CU they starve (queue priority does not pre-empt
  * resident workgroups).  sr_stream_create returns a hipStream_t whose kernels may only run on the CUs whose bit is

@@ -24,6 +24,7 @@ SIGNATURES = {
     'sr_destroy': (None, [c_void_p]),
     'sr_set_stream': (c_int, [c_void_p, c_void_p]),
     'sr_sync': (c_int, [c_void_p]),
+    'sr_set_option': (c_int, [c_void_p, c_char_p, c_int]),
     'sr_stream_create': (c_int, [c_void_p, POINTER(ctypes.c_uint32), c_int, c_int, POINTER(c_void_p)]),
     'sr_stream_destroy': (c_int, [c_void_p, c_void_p]),
     'sr_device_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int64), POINTER(c_int), c_char_p, c_int]),
@@ -75,6 +76,32 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64.so.7; /opt/rocm has another one with
+    the same soname, and whichever is loaded first serves both this library and torch.  If this library came first
+    it would bind the system runtime, torch would later bring up its bundled copy as a SECOND runtime, and that one
+    finds no GPU ("No HIP GPUs are available").  So when torch is installed its runtime is loaded first (without
+    importing torch); device pointers and streams are then interchangeable between the two."""
+    import importlib.util
+    import sys
+    if 'torch' in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], 'lib')
+    for name in ('libhsa-runtime64.so', 'libamdhip64.so'):
+        path = os.path.join(libdir, name)
+        if os.path.isfile(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load():
     """Load the shared library (once) and attach the signatures."""
     global _lib
@@ -84,6 +111,7 @@ def load():
         raise SpinRelaxHipError(
             '%s not found: build it with `python -m spinrelax_amd.build` (needs hipcc). '
             'spinrelax_amd has no CPU fallback.' % LIB_PATH)
+    _share_hip_runtime_with_torch()
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as exc:

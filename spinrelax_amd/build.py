@@ -15,6 +15,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', 
 # sr_ct.hip: the SLP vectoriser packs the FMAs of the C(t) inner loop into v_pk_fma_f32, whose operand pairs then
 # need ~1 v_mov per FMA (rocprofv3: 4.8e9 VALU instructions for 2.5e9 FMAs); plain v_fma_f32 issues at the same rate.
 EXTRA = {'sr_ct.hip': ['-fno-slp-vectorize']}
+if os.environ.get('SR_FIT_DEV_FAST'):          # development: only the order-search variants the benchmark uses
+    EXTRA['sr_fit.hip'] = ['-DSR_FIT_DEV_FAST']
 
 
 def _stale(target, deps):

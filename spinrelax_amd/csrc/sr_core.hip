@@ -1,5 +1,6 @@
 // sr_core.hip -- context, device memory, stream and HIP-event timing of libspinrelax_hip.so
 #include "sr_internal.h"
+#include <cstring>
 
 static thread_local char g_err[1024] = "";
 
@@ -56,6 +57,8 @@ sr_ctx *sr_create(int device)
     memset(ctx, 0, sizeof(*ctx));
     ctx->device = device;
     ctx->stream = nullptr;
+    ctx->fit_waves = 4;
+    ctx->fit_lds = 1;
     if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) {
         sr_set_error("hipGetDeviceProperties failed");
         delete ctx;
@@ -84,6 +87,24 @@ void sr_destroy(sr_ctx *ctx)
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     delete ctx;
+}
+
+int sr_set_option(sr_ctx *ctx, const char *name, int value)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(name != nullptr, -2, "sr_set_option: name is NULL");
+    if (!strcmp(name, "fit_waves")) {
+        SR_REQUIRE(value == 1 || value == 2 || value == 4, -3, "sr_set_option: fit_waves must be 1, 2 or 4");
+        ctx->fit_waves = value;
+        return 0;
+    }
+    if (!strcmp(name, "fit_lds")) {
+        SR_REQUIRE(value == 0 || value == 1, -3, "sr_set_option: fit_lds must be 0 or 1");
+        ctx->fit_lds = value;
+        return 0;
+    }
+    sr_set_error("sr_set_option: unknown option '%s'", name);
+    return -3;
 }
 
 int sr_set_stream(sr_ctx *ctx, void *hip_stream)

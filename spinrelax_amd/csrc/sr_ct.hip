@@ -121,6 +121,9 @@ template <int W>
 __global__ __launch_bounds__(W * 64) void k_ct_palmer(CtArgs a)
 {
     extern __shared__ __align__(16) float lds[];
+    // This is the throughput kernel of the pipeline; the fit wavefronts of the previous batch share its SIMDs.  Raised
+    // issue priority makes them fill the slots this kernel leaves idle instead of taking turns with it.
+    __builtin_amdgcn_s_setprio(3);
     const int Fp = a.Fp, Hf = (Fp >> 3) * 12, F = a.F;
     const int tid = threadIdx.x;
     const int lane = tid & 63;

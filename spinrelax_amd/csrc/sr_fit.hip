@@ -915,7 +915,7 @@ __device__ __noinline__ void search_order(const R T, const SearchArgs &a, int j,
 }
 
 template <int NMAX, int W, bool LDS>
-__global__ __launch_bounds__(W * 64) void k_order_search(SearchArgs a)
+__global__ __launch_bounds__(W * 64, 2) void k_order_search(SearchArgs a)
 {
     const int res = blockIdx.x;
     const int tid = threadIdx.x;
@@ -1003,13 +1003,12 @@ __global__ __launch_bounds__(W * 64) void k_order_search(SearchArgs a)
     }
 }
 
-template <int NMAX>
-int launch_search(sr_ctx *ctx, const SearchArgs &a)
+template <int NMAX, int W>
+int launch_search_w(sr_ctx *ctx, const SearchArgs &a)
 {
-    constexpr int W = 4;
     const size_t lds_small = (size_t)W * kRedStride * sizeof(double);
     const size_t lds_full = lds_small + (size_t)3 * a.L * sizeof(double);
-    if (lds_full <= sr_lds_limit(ctx)) {
+    if (ctx->fit_lds && lds_full <= sr_lds_limit(ctx)) {
         if (lds_full > 64 * 1024)
             SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_order_search<NMAX, W, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
@@ -1019,6 +1018,16 @@ int launch_search(sr_ctx *ctx, const SearchArgs &a)
     }
     SR_HIP(hipGetLastError());
     return 0;
+}
+
+template <int NMAX>
+int launch_search(sr_ctx *ctx, const SearchArgs &a)
+{
+    switch (ctx->fit_waves) {
+        case 1: return launch_search_w<NMAX, 1>(ctx, a);
+        case 2: return launch_search_w<NMAX, 2>(ctx, a);
+        default: return launch_search_w<NMAX, 4>(ctx, a);
+    }
 }
 
 // residual + analytic Jacobian for arbitrary parameter sets
@@ -1142,7 +1151,7 @@ int sr_expfit_order_search_f64_dev(sr_ctx *ctx, const double *t, const double *C
     for (int j = nOrders; j < kMaxOrders; ++j) { a.orders[j] = 0; a.tau_off[j] = 0; }
     const size_t lds_full = ((size_t)4 * kRedStride + (size_t)3 * L) * sizeof(double);
     double *fws = work;
-    if (!fws && lds_full > sr_lds_limit(ctx)) {
+    if (!fws && (!ctx->fit_lds || lds_full > sr_lds_limit(ctx))) {
         fws = (double *)sr_workspace(ctx, SR_WS_FIT, (size_t)nRes * L * sizeof(double));
         if (!fws) return -5;
     }
@@ -1152,9 +1161,14 @@ int sr_expfit_order_search_f64_dev(sr_ctx *ctx, const double *t, const double *C
     a.Pmax = pmax; a.Kmax = pmax / 2;
     a.popt = popt; a.dP = dP; a.chisq = chisq; a.status = status; a.nfev = nfev; a.best = best;
     a.sel_S2 = sel_S2; a.sel_C = sel_C; a.sel_tau = sel_tau; a.sel_chi = sel_chi; a.sel_K = sel_K; a.fws = fws;
+#ifdef SR_FIT_DEV_FAST
+    SR_REQUIRE(pmax <= 9, -3, "development build: orders up to 9 only");
+    return launch_search<9>(ctx, a);
+#else
     if (pmax <= 5) return launch_search<5>(ctx, a);
     if (pmax <= 9) return launch_search<9>(ctx, a);
     return launch_search<11>(ctx, a);
+#endif
 }
 
 int sr_expfit_order_search_f64(sr_ctx *ctx, const double *t, const double *C, const double *sigma, int nRes, int L,

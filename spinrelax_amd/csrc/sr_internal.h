@@ -17,6 +17,9 @@ struct sr_ctx {
     // growable device workspaces, one per purpose, reused across calls (no hipMalloc in steady state)
     void *slot[SR_NSLOTS];
     size_t slot_bytes[SR_NSLOTS];
+    // tuning (sr_set_option)
+    int fit_waves;      // waves per residue in the model-order search: 1, 2 or 4
+    int fit_lds;        // 1: stage t, y, 1/sigma of a residue in LDS when it fits; 0: read them from global memory
 };
 
 enum {

@@ -57,6 +57,9 @@ class Context:
     def sync(self):
         check(self.lib.sr_sync(self.h), 'sr_sync')
 
+    def set_option(self, name, value):
+        check(self.lib.sr_set_option(self.h, name.encode(), int(value)), 'sr_set_option')
+
     def stream_create(self, cu_mask_words=None, priority=0):
         """hipStream_t handle (int); cu_mask_words = iterable of 32-bit words, bit set = CU usable."""
         out = ctypes.c_void_p()

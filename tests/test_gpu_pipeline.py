@@ -1,0 +1,99 @@
+"""
+GPU tests of the device-resident pipeline (spinrelax_amd/pipeline.py): vectors in HBM -> C(t) -> histogram -> model-order
+search -> R1/R2/NOE without the host in between, serial and with several batches in flight on a partitioned chip.
+The pipeline must give exactly what the staged C-ABI calls give (those are checked against the oracle and the
+reference's golden vectors in test_gpu_parity.py), and the same answer for every batch however they overlap.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def setup():
+    import torch
+    from spinrelax_amd import synth
+    from spinrelax_amd.hip import Context
+    s = synth.config_shapes(1)
+    vecs = synth.synth_config(1)
+    ctx = Context(0)
+    dev = torch.device('cuda', 0)
+    return dict(torch=torch, synth=synth, ctx=ctx, dev=dev, s=s, vecs=vecs, dvecs=torch.from_numpy(vecs).to(dev))
+
+
+def _pipe(st, depth, aniso=True, reserve=0, only=False):
+    from spinrelax_amd.pipeline import DevicePipeline
+    s, synth = st['s'], st['synth']
+    V = st['vecs'].shape[1]
+    return DevicePipeline(st['ctx'], st['dev'], s['frames'], V, s['R'], s['F'], s['dt'], q_rot=synth.Q_EXT if aniso else None,
+                          Diso=synth.DISO, aniso=synth.DANI if aniso else None, field_MHz=(synth.FIELD_MHZ, 500.0),
+                          zeta=synth.ZETA, depth=depth, stream=st['torch'].cuda.Stream(device=st['dev']), reserve_cus=reserve,
+                          fits_on_reserved_only=only)
+
+
+@pytest.mark.parametrize('aniso', [True, False])
+def test_pipeline_step_equals_staged_calls(setup, aniso):
+    from spinrelax_amd import ct as hostct
+    from spinrelax_amd import fitting_Ct_functions as fitCt
+    from spinrelax_amd import _hostmath as hm
+    st = setup
+    ctx, s, synth, vecs = st['ctx'], st['s'], st['synth'], st['vecs']
+    pipe = _pipe(st, 1, aniso)
+    out = pipe.step(st['dvecs']).copy()
+    st['torch'].cuda.synchronize()
+    sl = pipe.slots[0]
+    V = vecs.shape[1]
+    # kernel 1 and 2: same kernels behind the host-pointer entry points
+    ctx.set_stream(0)
+    Ct, dCt = ctx.ct_palmer(vecs, s['R'], s['F'])
+    assert np.array_equal(sl.Ct.cpu().numpy(), Ct) and np.array_equal(sl.dCt.cpu().numpy(), dCt)
+    if aniso:
+        e = hostct.lambert_edges()
+        hist, vecsum, outer = ctx.rotate_hist(vecs[: s['N']], np.array(synth.Q_EXT), e[0], e[1], block_len=s['F'])
+        assert np.array_equal(sl.hist.cpu().numpy().reshape(hist.shape), hist)
+        assert np.array_equal(sl.vecsum.cpu().numpy(), vecsum)
+    # kernel 3b: the search on the same C(t)
+    t = np.ascontiguousarray(np.broadcast_to(hostct.calculate_dt(s['dt'], s['F'] * s['dt']), (V, s['L'])))
+    ref = fitCt.order_search_device(t, np.ascontiguousarray(Ct.T), np.ascontiguousarray(dCt.T), pipe.listDoG, 0.5, ctx=ctx)
+    r = sl.result
+    for k in ('best', 'K', 'S2', 'C', 'tau'):
+        assert np.array_equal(r[k], ref[k]), k
+    assert np.array_equal(r['chi'], ref['chi'], equal_nan=True)
+    # kernel 3a: zeta scaling on load == scaling on the host first
+    oms, fdd, fcsa, tf, gr = pipe._relax_consts
+    z = synth.ZETA
+    if aniso:
+        Dpar, Dperp = hm.symmtop_from_iso(synth.DISO, synth.DANI)
+        want, _ = ctx.relax(2, [Dpar, Dperp], oms, fdd, fcsa, tf, gr, z * ref['S2'], z * ref['C'], ref['tau'], ref['K'],
+                            binvecs=pipe.binvecs, weights=hist.reshape(V, -1), noe_mode=0)
+    else:
+        want, _ = ctx.relax(1, [synth.DISO], oms, fdd, fcsa, tf, gr, z * ref['S2'], z * ref['C'], ref['tau'], ref['K'])
+    assert out.shape == want.shape == (2, V, 4, 2)
+    assert np.array_equal(out, want, equal_nan=True)
+    assert np.all(np.isfinite(out[:, :, :3, 0])) and np.all(out[:, :, 0, 0] > 0)
+    pipe.close()
+
+
+@pytest.mark.parametrize('depth,reserve,only', [(2, 0, False), (4, 16, False), (3, 32, True)])
+def test_pipeline_batches_in_flight_are_identical_and_ordered(setup, depth, reserve, only):
+    st = setup
+    serial = _pipe(st, 1)
+    want = serial.step(st['dvecs']).copy()
+    want_best = serial.fit_best.copy()
+    serial.close()
+    pipe = _pipe(st, depth, True, reserve, only)
+    assert pipe.reserve_cus == reserve
+    seen = []
+
+    def on_finished(slot):
+        seen.append((pipe.slots.index(slot), slot.relax_out.copy(), slot.result['best'].copy(), slot.Ct.cpu().numpy().sum()))
+    nb = 2 * depth + 1
+    pipe.run(st['dvecs'], nb, None, on_finished)
+    st['torch'].cuda.synchronize()
+    assert [i for i, *_ in seen] == [k % depth for k in range(nb)]
+    for _, relax, best, _ in seen:
+        assert np.array_equal(relax, want, equal_nan=True)
+        assert np.array_equal(best, want_best)
+    assert len({c for *_, c in seen}) == 1
+    pipe.close()

@@ -74,6 +74,7 @@ SIGNATURES = {
 }
 
 _lib = None
+LIB_PATH = os.environ.get('SPINRELAX_HIP_LIB', LIB_PATH)      # alternative build of the same ABI
 
 
 def _share_hip_runtime_with_torch():

@@ -43,6 +43,35 @@ struct FitArgs {
 
 __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 
+// Two instruction-count reductions that are implemented, give bit-identical fits, and are OFF because they lose on
+// gfx950 (cfg3 benchmark data, model-order search alone / whole pipeline step):
+//   SR_FIT_LEADER=1  only the leader wave runs the n x n algebra and broadcasts the trial point   14.5 ms / 10.5 ms
+//   SR_FIT_MARK=1,2  shared-divisor (Markstein) division for t/tau (1) and the FD quotient (2)     12.7, 16.8 / 10.4, 11.0
+//   both off                                                                                      12.4 ms / 10.4 ms
+// The kernel lives at the 256-register limit of two waves per SIMD; the extra live values (reciprocals, the
+// broadcast state) turn into scratch spills inside the Jacobian loop that cost more than the instructions saved.
+#ifndef SR_FIT_LEADER
+#define SR_FIT_LEADER 0
+#endif
+#ifndef SR_FIT_MARK
+#define SR_FIT_MARK 0
+#endif
+
+// a / b for a divisor b shared by many numerators, with r = 1.0 / b computed once (correctly rounded).  q0 = a*r is
+// within 2 ulp; one residual correction makes it faithful, the second gives the correctly rounded quotient
+// (Markstein 1990; the same tail v_div_fmas_f64 executes) -- 5 instructions instead of the ~14 of a full IEEE
+// division with its scaling.  Exception the theorem leaves open: divisors whose significand is all ones.
+// Huge quotients (tau at its lower bound) take the ordinary division.
+__device__ __forceinline__ double div_shared(double a, double b, double r)
+{
+    double q = a * r;
+    if (!(fabs(q) <= 1e290)) return a / b;
+    double e = fma(-b, q, a);
+    q = fma(e, r, q);
+    e = fma(-b, q, a);
+    return fma(e, r, q);
+}
+
 // ---- model: curvefit_exponential, fitting_Ct_functions.py:419-427 -----------------------------
 template <int N>
 struct Model {
@@ -64,6 +93,17 @@ struct Model {
 #pragma clang fp contract(off)
 #pragma unroll
         for (int k = 0; k < K; ++k) e[k] = exp((-1.0 * t) / x[K + k]);
+    }
+    // the same with rtau[k] = 1.0 / tau_k hoisted out of the loop over the data points
+    __device__ static __forceinline__ void recips(const double *x, double *rtau)
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) rtau[k] = 1.0 / x[K + k];
+    }
+    __device__ static __forceinline__ void exps(const double *x, const double *rtau, double t, double *e)
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) e[k] = exp(SR_FIT_MARK >= 1 ? div_shared(-1.0 * t, x[K + k], rtau[k]) : (-1.0 * t) / x[K + k]);
     }
     __device__ static __forceinline__ double value(const double *x, const double *e)
     {
@@ -403,17 +443,21 @@ extern __shared__ __align__(16) double fit_smem[];
 // with one wave per SIMD and nothing to hide the latency behind, which was most of the ~12 us an iteration cost
 // even at n = 2.  LDS = false (L too long for LDS): global memory, weights precomputed into the work array.
 constexpr int kRedStride = kNmax * (kNmax + 1) / 2 + kNmax + 2;   // doubles per wave in the reduction scratch
+constexpr int kBcast = 16;
+__host__ __device__ constexpr size_t fit_lds_doubles(int W, int64_t L_staged) { return (size_t)W * kRedStride + kBcast + 3 * (size_t)L_staged; }
 
 template <int W, bool LDS>
 struct Residue {
     static constexpr int NTH = W * 64;
-    static constexpr int RED = W * kRedStride;
+    static constexpr int BC = W * kRedStride;          // kBcast doubles: leader wave -> workgroup broadcast
+    static constexpr int RED = BC + kBcast;            // start of the staged residue
 
     const double *tg, *yg, *wg;   // global (LDS == false)
     const double *sg;             // sigma of this residue (global) or null
     int L, tid;
 
     __device__ __forceinline__ double *red() const { return fit_smem; }
+    __device__ __forceinline__ double *bcast() const { return fit_smem + BC; }
     __device__ __forceinline__ double ld_t(int l) const { return LDS ? fit_smem[RED + l] : tg[l]; }
     __device__ __forceinline__ double ld_y(int l) const { return LDS ? fit_smem[RED + L + l] : yg[l]; }
     __device__ __forceinline__ double ld_w(int l) const { return LDS ? fit_smem[RED + 2 * L + l] : wg[l]; }
@@ -468,9 +512,11 @@ __device__ __forceinline__ double eval_f(const R &T, const double *x, bool &fini
     const int tid = T.tid, L = T.L;
     constexpr int NTH = R::NTH;
     double acc = 0.0, bad = 0.0;
+    double rtau[K > 0 ? K : 1];
+    M::recips(x, rtau);
     for (int l = tid; l < L; l += NTH) {
         double e[K > 0 ? K : 1];
-        M::exps(x, T.ld_t(l), e);
+        M::exps(x, rtau, T.ld_t(l), e);
         double f;
         {
 #pragma clang fp contract(off)
@@ -494,7 +540,7 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
     using M = Model<N>;
     const int tid = T.tid, L = T.L;
     constexpr int NTH = R::NTH;
-    double h[N], dx[N];
+    double h[N], dx[N], rdx[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         // _numdiff.py:_compute_absolute_step + _adjust_scheme_to_bounds('1-sided', num_steps=1)
@@ -508,7 +554,12 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
         if (!fitting) hi = (ud >= ld) ? ud : -ld;
         h[i] = hi;
         dx[i] = (x[i] + hi) - x[i];
+        rdx[i] = 1.0 / dx[i];
     }
+    double rtau[K > 0 ? K : 1], rtau_h[K > 0 ? K : 1];
+    M::recips(x, rtau);
+#pragma unroll
+    for (int k = 0; k < K; ++k) rtau_h[k] = 1.0 / (x[K + k] + h[K + k]);
     double Aacc[NT], gacc[N];
 #pragma unroll
     for (int i = 0; i < NT; ++i) Aacc[i] = 0.0;
@@ -517,7 +568,7 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
     for (int l = tid; l < L; l += NTH) {
         const double tl = T.ld_t(l), w = T.ld_w(l), yl = T.ld_y(l);
         double e[K > 0 ? K : 1], Jr[N], f0;
-        M::exps(x, tl, e);
+        M::exps(x, rtau, tl, e);
         {
 #pragma clang fp contract(off)
             f0 = w * (M::value(x, e) - yl);
@@ -532,16 +583,14 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
                 xi[i] = x[i] + h[i];
 #pragma unroll
                 for (int k = 0; k < K; ++k) ei[k] = e[k];
-                if (i >= K && i < 2 * K) {
-#pragma clang fp contract(off)
-                    ei[i - K] = exp((-1.0 * tl) / xi[i]);
-                }
+                if (i >= K && i < 2 * K)
+                    ei[i - K] = exp(SR_FIT_MARK >= 1 ? div_shared(-1.0 * tl, xi[i], rtau_h[i - K]) : (-1.0 * tl) / xi[i]);
                 double fi;
                 {
 #pragma clang fp contract(off)
                     fi = w * (M::value(xi, ei) - yl);
-                    Jr[i] = (fi - f0) / dx[i];
                 }
+                Jr[i] = SR_FIT_MARK >= 2 ? div_shared(fi - f0, dx[i], rdx[i]) : (fi - f0) / dx[i];
             }
         } else {
 #pragma unroll
@@ -584,6 +633,7 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
     constexpr int K = N / 2;
     constexpr int NT = N * (N + 1) / 2;
     const int m = T.L;
+    const bool leader = !SR_FIT_LEADER || (R::NTH == 64) || (T.tid < 64);
     double lb[N], ub[N];
     bool inb = true;
 #pragma unroll
@@ -646,31 +696,54 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
                 if (g_norm < P.gtol) { term = 1; term_set = true; }
                 if (term_set || nfev == max_nfev) break;
 
+                // The trust-region sub-problem (Cholesky per Levenberg parameter, reflective / Cauchy step selection) is
+                // a few thousand dependent float64 operations with no parallelism in it.  The leader wave solves it
+                // and broadcasts the trial point through LDS; the other waves wait at the barrier, which leaves their
+                // SIMDs to the C(t) wavefronts of the next batch that share the CU.
                 double d[N], g_h[N], B[NT];
-#pragma unroll
-                for (int i = 0; i < N; ++i) { d[i] = sqrt(v[i]); g_h[i] = d[i] * g[i]; }
-#pragma unroll
-                for (int i = 0; i < N; ++i)
-#pragma unroll
-                    for (int j = 0; j <= i; ++j)
-                        B[tri(i, j)] = (A[tri(i, j)] * d[i]) * d[j] + (i == j ? g[i] * dv[i] : 0.0);
                 const double theta = fmax(0.995, 1 - g_norm);
+                if (leader) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) { d[i] = sqrt(v[i]); g_h[i] = d[i] * g[i]; }
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+#pragma unroll
+                        for (int j = 0; j <= i; ++j)
+                            B[tri(i, j)] = (A[tri(i, j)] * d[i]) * d[j] + (i == j ? g[i] * dv[i] : 0.0);
+                }
 
                 double actual_reduction = -1.0, cost_new = cost;
                 double xn[N];
                 while (actual_reduction <= 0 && nfev < max_nfev) {
-                    double p_h[N], p[N], step[N], step_h[N], predicted;
-                    solve_tr<N>(B, g_h, m, Delta, alpha, p_h);
+                    double predicted, step_h_norm, step_norm;
+                    if (leader) {
+                        double p_h[N], p[N], step[N], step_h[N];
+                        solve_tr<N>(B, g_h, m, Delta, alpha, p_h);
 #pragma unroll
-                    for (int i = 0; i < N; ++i) p[i] = d[i] * p_h[i];
-                    select_step<N>(x, B, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h, predicted);
+                        for (int i = 0; i < N; ++i) p[i] = d[i] * p_h[i];
+                        select_step<N>(x, B, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h, predicted);
 #pragma unroll
-                    for (int i = 0; i < N; ++i) xn[i] = x[i] + step[i];
-                    strictly_feasible<N>(xn, lb, ub, 0.0);
+                        for (int i = 0; i < N; ++i) xn[i] = x[i] + step[i];
+                        strictly_feasible<N>(xn, lb, ub, 0.0);
+                        step_h_norm = normN<N>(step_h);
+                        step_norm = normN<N>(step);
+                        if (SR_FIT_LEADER && R::NTH > 64 && T.tid == 0) {
+                            double *bc = T.bcast();
+#pragma unroll
+                            for (int i = 0; i < N; ++i) bc[i] = xn[i];
+                            bc[N] = predicted; bc[N + 1] = step_h_norm; bc[N + 2] = step_norm;
+                        }
+                    }
+                    if (SR_FIT_LEADER && R::NTH > 64) {
+                        __syncthreads();
+                        const double *bc = T.bcast();
+#pragma unroll
+                        for (int i = 0; i < N; ++i) xn[i] = bc[i];
+                        predicted = bc[N]; step_h_norm = bc[N + 1]; step_norm = bc[N + 2];
+                    }
                     bool finite2;
                     cost_new = eval_f<N>(T, xn, finite2);
                     nfev += 1;
-                    const double step_h_norm = normN<N>(step_h);
                     if (!finite2) {
                         Delta = 0.25 * step_h_norm;
                         continue;
@@ -684,7 +757,6 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
                     double Delta_new = Delta;
                     if (ratio < 0.25) Delta_new = 0.25 * step_h_norm;
                     else if (ratio > 0.75 && step_h_norm > 0.95 * Delta) Delta_new = Delta * 2.0;
-                    const double step_norm = normN<N>(step);
                     // check_termination
                     const bool ft = (actual_reduction < P.ftol * cost) && (ratio > 0.25);
                     const bool xt = step_norm < P.xtol * (P.xtol + normN<N>(x));
@@ -1006,8 +1078,8 @@ __global__ __launch_bounds__(W * 64, 2) void k_order_search(SearchArgs a)
 template <int NMAX, int W>
 int launch_search_w(sr_ctx *ctx, const SearchArgs &a)
 {
-    const size_t lds_small = (size_t)W * kRedStride * sizeof(double);
-    const size_t lds_full = lds_small + (size_t)3 * a.L * sizeof(double);
+    const size_t lds_small = fit_lds_doubles(W, 0) * sizeof(double);
+    const size_t lds_full = fit_lds_doubles(W, a.L) * sizeof(double);
     if (ctx->fit_lds && lds_full <= sr_lds_limit(ctx)) {
         if (lds_full > 64 * 1024)
             SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_order_search<NMAX, W, true>),
@@ -1070,9 +1142,8 @@ int launch_trf(sr_ctx *ctx, const FitArgs &a)
     // 4 waves = one per SIMD of a CU: the redundant serial algebra is VALU-issue bound, a second wave per
     // SIMD doubles its time (measured at n = 9: 68 / 41 / 28 / 51 us per iteration for W = 1 / 2 / 4 / 8)
     constexpr int W = 4;
-    constexpr int RED = W * kRedStride;
-    const size_t lds_small = (size_t)RED * sizeof(double);
-    const size_t lds_full = lds_small + (size_t)3 * a.L * sizeof(double);
+    const size_t lds_small = fit_lds_doubles(W, 0) * sizeof(double);
+    const size_t lds_full = fit_lds_doubles(W, a.L) * sizeof(double);
     if (lds_full <= sr_lds_limit(ctx)) {
         if (lds_full > 64 * 1024)
             SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trf<N, W, true>),
@@ -1149,7 +1220,7 @@ int sr_expfit_order_search_f64_dev(sr_ctx *ctx, const double *t, const double *C
         pmax = orders[j] > pmax ? orders[j] : pmax;
     }
     for (int j = nOrders; j < kMaxOrders; ++j) { a.orders[j] = 0; a.tau_off[j] = 0; }
-    const size_t lds_full = ((size_t)4 * kRedStride + (size_t)3 * L) * sizeof(double);
+    const size_t lds_full = fit_lds_doubles(4, L) * sizeof(double);
     double *fws = work;
     if (!fws && (!ctx->fit_lds || lds_full > sr_lds_limit(ctx))) {
         fws = (double *)sr_workspace(ctx, SR_WS_FIT, (size_t)nRes * L * sizeof(double));

@@ -39,6 +39,21 @@ PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector = FP32 matr
 PEAK_HBM_GBS = 8000.0
 
 
+def measured_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, produced by
+    scripts/make_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_cfg3_hbm_counters.json')))
+    if not files:
+        return None, None
+    with open(files[-1]) as fp:
+        d = json.load(fp)
+    for k, v in d.get('kernels', {}).items():
+        if k.startswith(kernel_prefix):
+            return v['hbm_bytes_corrected'], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -210,6 +225,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = triples * world / (elapsed / args.steps)
         achieved = 8.0 * triples / (ct_ms * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic('k_ct_palmer') if cfg == 3 and V == 512 else (None, None)
         best, _ = pipe.fit_best, None
         res = {
             'metric': 'frame-vector-lag triples/s, C(t) + fit + R1/R2/NOE pipeline',
@@ -223,7 +239,8 @@ def main():
                        'vectors_per_gpu': V, 'exact_triples_per_gpu': triples, 'sharding': 'vectors (no data-path collective; all-gather of results)', 'batches_in_flight': pipe.depth, 'cus_reserved_for_fits': pipe.reserve_cus},
             'roofline': {'bound': 'valu-fp32 (non-MFMA vector FMA; FP32 MFMA peak is the same 157.3)', 'kernel': 'k_ct_palmer',
                          'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS,
-                         'traffic': None, 'kernel_ms': ct_ms, 'flop_per_triple': 8,
+                         'traffic': traffic, 'traffic_unit': 'bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)', 'traffic_source': traffic_src,
+                         'algorithmic_bytes': 12 * s['N'] * V + 8 * s['R'] * s['L'] * V, 'kernel_ms': ct_ms, 'flop_per_triple': 8,
                          'streaming_equiv_GBps': 24.0 * triples / (ct_ms * 1e-3) / 1e9,
                          'streaming_equiv_frac_of_hbm': 24.0 * triples / (ct_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
             'stages_ms': {'ct_palmer': ct_ms, 'rotate_hist': hist_ms,

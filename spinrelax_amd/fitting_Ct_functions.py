@@ -312,8 +312,8 @@ class autoCorrelations:
         print("Number of targets loaded:", self.nTargets)
 
     def fit_all(self, listDoG=[2, 3, 5, 7, 9], chiSqThreshold=0.5, nc=-1, bUseSFast=True, fp=sys.stdout, ctx=None):
-        """The per-residue loop of calculate-fitted-Ct.py:161-178, batched: every residue advances through
-        the model orders together, each order being ONE GPU launch over the residues still searching."""
+        """The per-residue loop of calculate-fitted-Ct.py:161-178 as ONE GPU launch: every residue runs through the
+        model orders, quality checks and the accept / reject rule on the device (sr_expfit_order_search_f64)."""
         keys = list(self.DeltaT.keys())
         t = np.array([self.DeltaT[k] for k in keys], dtype=float)
         y = np.array([self.Decay[k] for k in keys], dtype=float)
@@ -418,6 +418,26 @@ def order_search_device(t, y, dy, listDoG=(2, 3, 5, 7, 9), chiSqThreshold=0.5, c
     if not np.all(t[:, -1] == t[0, -1]):
         raise ValueError('order_search_device: residues with different final times need separate calls (tau bound)')
     return _ctx(ctx).order_search(t, y, dy, listDoG, tau_guesses(t, listDoG), tau_max, chiSqThreshold)
+
+
+def order_search_device_results(t, y, dy, listDoG=(2, 3, 5, 7, 9), chiSqThreshold=0.5, ctx=None):
+    """order_search_device, returned in the shape order_search_batch uses: (best (n,), list of per-order batch
+    results with the initial guesses and the three quality flags re-derived on the host for the report)."""
+    t = np.atleast_2d(np.asarray(t, dtype=float))
+    y = np.atleast_2d(np.asarray(y, dtype=float))
+    if t.shape[0] == 1 and y.shape[0] > 1:
+        t = np.ascontiguousarray(np.broadcast_to(t, y.shape))
+    dev = order_search_device(t, y, dy, listDoG, chiSqThreshold, ctx)
+    per_order = []
+    for j, nP in enumerate(listDoG):
+        tried = dev['status'][j] != -100
+        if not tried.any():
+            break
+        req = fit_request(t, y, nP, tried)
+        idx = req['idx']
+        per_order.append(fit_collect(req, dev['popt'][j][idx, :nP], dev['dP'][j][idx, :nP], dev['chisq'][j][idx],
+                                     dev['status'][j][idx]))
+    return dev['best'].astype(int), per_order
 
 
 def fit_request(t, y, nParams, active=None):
@@ -581,9 +601,17 @@ def order_search_batch(t, y, runner, listDoG=(2, 3, 5, 7, 9), chiSqThreshold=0.5
 
 def optimised_curve_fitting_batch(names, t, y, dy, listDoG=(2, 3, 5, 7, 9), chiSqThreshold=0.5, fp=sys.stdout, ctx=None,
                                   return_trials=False, runner=None):
-    """Convenience wrapper: list of selected fit dicts (None where no order was ever satisfactory)."""
-    run = runner if runner is not None else host_runner(t, y, dy, ctx)
-    best, per_order = order_search_batch(t, y, run, listDoG, chiSqThreshold)
+    """optimised_curve_fitting for every residue: list of selected fit dicts (None where no order was ever
+    satisfactory).  Default: the one-launch search on the GPU (sr_expfit_order_search_f64); with a `runner` the
+    host-driven state machine OrderSearchBatch is used instead (one solver call per model order; bit-identical
+    results, tests/test_gpu_parity.py)."""
+    tt = np.atleast_2d(np.asarray(t, dtype=float))
+    if runner is None and len(listDoG) <= 8 and np.all(tt[:, -1] == tt[0, -1]):
+        best, per_order = order_search_device_results(t, y, dy, listDoG, chiSqThreshold, ctx)
+    else:
+        # caller-supplied solver, more than 8 orders, or residues whose time axes end differently (one tau bound each)
+        run = runner if runner is not None else host_runner(t, y, dy, ctx)
+        best, per_order = order_search_batch(t, y, run, listDoG, chiSqThreshold)
     results = []
     for i in range(y.shape[0]):
         if fp is not None:

@@ -444,13 +444,20 @@ extern __shared__ __align__(16) double fit_smem[];
 // even at n = 2.  LDS = false (L too long for LDS): global memory, weights precomputed into the work array.
 constexpr int kRedStride = kNmax * (kNmax + 1) / 2 + kNmax + 2;   // doubles per wave in the reduction scratch
 constexpr int kBcast = 16;
-__host__ __device__ constexpr size_t fit_lds_doubles(int W, int64_t L_staged) { return (size_t)W * kRedStride + kBcast + 3 * (size_t)L_staged; }
+constexpr int kMat = kNmax * (kNmax + 1) / 2;                        // one packed symmetric n x n matrix
+__host__ __device__ constexpr size_t fit_lds_doubles(int W, int64_t L_staged)
+{
+    return (size_t)W * kRedStride + kBcast + 2 * kMat + 3 * (size_t)L_staged;
+}
 
 template <int W, bool LDS>
 struct Residue {
     static constexpr int NTH = W * 64;
+    static constexpr int NW = W;
     static constexpr int BC = W * kRedStride;          // kBcast doubles: leader wave -> workgroup broadcast
-    static constexpr int RED = BC + kBcast;            // start of the staged residue
+    static constexpr int MA = BC + kBcast;             // J^T J of the current point (packed), shared by all threads
+    static constexpr int MB = MA + kMat;               // the scaled trust-region matrix B
+    static constexpr int RED = MB + kMat;              // start of the staged residue
 
     const double *tg, *yg, *wg;   // global (LDS == false)
     const double *sg;             // sigma of this residue (global) or null
@@ -458,6 +465,11 @@ struct Residue {
 
     __device__ __forceinline__ double *red() const { return fit_smem; }
     __device__ __forceinline__ double *bcast() const { return fit_smem + BC; }
+    // The two n x n matrices every thread would otherwise hold in registers (90 VGPRs each at n = 9: the kernel sat
+    // at the 256-register limit and spilled ~1 GB per launch to scratch).  They are workgroup-uniform, read with
+    // broadcast ds_read_b64 whose addresses are known up front.
+    __device__ __forceinline__ double *matA() const { return fit_smem + MA; }
+    __device__ __forceinline__ double *matB() const { return fit_smem + MB; }
     __device__ __forceinline__ double ld_t(int l) const { return LDS ? fit_smem[RED + l] : tg[l]; }
     __device__ __forceinline__ double ld_y(int l) const { return LDS ? fit_smem[RED + L + l] : yg[l]; }
     __device__ __forceinline__ double ld_w(int l) const { return LDS ? fit_smem[RED + 2 * L + l] : wg[l]; }
@@ -607,16 +619,37 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
             for (int j = 0; j <= i; ++j) Aacc[tri(i, j)] += Jr[i] * Jr[j];
         }
     }
-    double all[NT + N];
+    // workgroup sums in the fixed order of block_sums (lanes by DPP butterfly, then waves 0..W-1): J^T J goes to the
+    // shared matrix in LDS (element k by thread k), J^T f to every thread's registers
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        double *r = T.red();
 #pragma unroll
-    for (int i = 0; i < NT; ++i) all[i] = Aacc[i];
+        for (int k = 0; k < NT; ++k) {
+            const double w = wsum(Aacc[k]);
+            if (lane == 0) r[wave * kRedStride + k] = w;
+        }
 #pragma unroll
-    for (int i = 0; i < N; ++i) all[NT + i] = gacc[i];
-    T.template block_sums<NT + N>(all);
+        for (int k = 0; k < N; ++k) {
+            const double w = wsum(gacc[k]);
+            if (lane == 0) r[wave * kRedStride + NT + k] = w;
+        }
+        __syncthreads();
+        for (int k = tid; k < NT; k += NTH) {
+            double acc = r[k];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) A[i] = all[i];
+            for (int w = 1; w < R::NW; ++w) acc += r[w * kRedStride + k];
+            A[k] = acc;
+        }
 #pragma unroll
-    for (int i = 0; i < N; ++i) g[i] = all[NT + i];
+        for (int k = 0; k < N; ++k) {
+            double acc = r[NT + k];
+#pragma unroll
+            for (int w = 1; w < R::NW; ++w) acc += r[w * kRedStride + NT + k];
+            g[k] = acc;
+        }
+        __syncthreads();
+    }
 }
 
 struct SolveParams {
@@ -646,9 +679,8 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
     status = -99;
     nfev = 0;
     double cost = INFINITY;
-    double A[NT], g[N];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) A[i] = 0.0;
+    double *A = T.matA(), *B = T.matB();     // LDS, workgroup-uniform
+    double g[N];
     bool have_fit = false;
 
     if (!inb) {
@@ -700,17 +732,18 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
                 // a few thousand dependent float64 operations with no parallelism in it.  The leader wave solves it
                 // and broadcasts the trial point through LDS; the other waves wait at the barrier, which leaves their
                 // SIMDs to the C(t) wavefronts of the next batch that share the CU.
-                double d[N], g_h[N], B[NT];
+                double d[N], g_h[N];
                 const double theta = fmax(0.995, 1 - g_norm);
-                if (leader) {
 #pragma unroll
-                    for (int i = 0; i < N; ++i) { d[i] = sqrt(v[i]); g_h[i] = d[i] * g[i]; }
+                for (int i = 0; i < N; ++i) { d[i] = sqrt(v[i]); g_h[i] = d[i] * g[i]; }
 #pragma unroll
-                    for (int i = 0; i < N; ++i)
+                for (int i = 0; i < N; ++i)
 #pragma unroll
-                        for (int j = 0; j <= i; ++j)
-                            B[tri(i, j)] = (A[tri(i, j)] * d[i]) * d[j] + (i == j ? g[i] * dv[i] : 0.0);
-                }
+                    for (int j = 0; j <= i; ++j) {
+                        const double b = (A[tri(i, j)] * d[i]) * d[j] + (i == j ? g[i] * dv[i] : 0.0);
+                        if (T.tid == 0) B[tri(i, j)] = b;
+                    }
+                __syncthreads();
 
                 double actual_reduction = -1.0, cost_new = cost;
                 double xn[N];
@@ -986,8 +1019,11 @@ __device__ __noinline__ void search_order(const R T, const SearchArgs &a, int j,
     }
 }
 
+#ifndef SR_FIT_WAVES_EU
+#define SR_FIT_WAVES_EU 2     // wavefronts per SIMD the register budget allows: 2 -> 256 VGPRs, 3 -> 168
+#endif
 template <int NMAX, int W, bool LDS>
-__global__ __launch_bounds__(W * 64, 2) void k_order_search(SearchArgs a)
+__global__ __launch_bounds__(W * 64, SR_FIT_WAVES_EU) void k_order_search(SearchArgs a)
 {
     const int res = blockIdx.x;
     const int tid = threadIdx.x;

@@ -64,6 +64,14 @@ int          sr_timer_stop_ms(sr_ctx *, float *elapsed_ms);     /* synchronises 
  * vector range [v0, v0+nV): the shard a GPU owns.  Npad >= N, Npad % 4 == 0. */
 int sr_pack_soa_f32_dev(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
                         float *soa, int64_t Npad);
+/* The same with per-frame de-tumbling folded in: frame n is rotated by the unit
+ * quaternion quat[n] = (w, x, y, z) -- rotate_vector_simd(v, q[:, None, :]), transforms3d_supplement.py:270-296, in
+ * float64 -- before it is rounded into the float32 planes.  quat: DEVICE pointer, (N, 4) float64, already
+ * normalised (vecnorm_NDarray).  With q = conj(q_orient(t)) from a PLUMED colvar-qorient file
+ * (plumedcolvario.py:24-81) the planes hold body-frame vectors: lab-frame vectors + orientation trajectory in,
+ * C(t) of the internal motion out, no superposition step (calculate-Ct-from-traj.py:466-467) needed. */
+int sr_pack_soa_rot_f32_dev(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
+                            const double *quat, float *soa, int64_t Npad);
 
 /* ---- kernel 1: Palmer-chunked P2 autocorrelation ------------------------------------------
  * Replaces calculate_Ct_Palmer (calculate-Ct-from-traj.py:200-238) after reformat_vecs_by_tau
@@ -106,6 +114,9 @@ int sr_rotate_hist_f32(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, int
 /* rotated vectors themselves, float64 (N, nV, 3) like the reference returns (for --vecDist output). */
 int sr_rotate_vectors_f32(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
                           const double *q, double *out);
+/* one quaternion per frame: quat (N, 4) float64 host array, already normalised; out (N, nV, 3) float64. */
+int sr_rotate_vectors_perframe_f32(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
+                                   const double *quat, double *out);
 
 /* ---- kernel 3b: multi-exponential C(t) model --------------------------------------------
  * Model of curvefit_exponential (fitting_Ct_functions.py:419-427): params = [C_1..C_K, tau_1..tau_K

@@ -49,6 +49,10 @@ def build_parser():
     p.add_argument('--fitsel', type=str, dest='fittxt', default='custom occupancy', help='MDTraj selection used for the superposition.')
     p.add_argument('--help_sel', action='store_true', help='Display help for selection texts and exit.')
     p.add_argument('--dt', type=float, default=10.0, help='[extension] frame spacing in ps for .npy vector input.')
+    p.add_argument('--qfile', type=str, nargs='+', default=None,
+                   help='[extension, SURVEY 8(f)-1] PLUMED colvar-qorient file(s), one per trajectory file (fields time q.w q.x q.y q.z): '
+                        'the fitted (body-frame) vectors are the lab-frame vectors rotated on the GPU by the inverse orientation '
+                        'quaternion of every frame, instead of coming from a superposition.')
     p.add_argument('--exact', action='store_true', help='[extension] float64 validation mode of the C(t) kernel.')
     return p
 
@@ -153,6 +157,19 @@ def main():
         resXH, vecXH, vecXHfit, deltaT = load_vector_files(args.infn, args.dt)
     else:
         resXH, vecXH, vecXHfit, deltaT = load_mdtraj(args)
+    if args.qfile is not None:
+        from spinrelax_amd import plumedcolvario
+        if len(args.qfile) != len(vecXH):
+            print("= = = ERROR: --qfile needs one orientation file per trajectory file!", file=sys.stderr)
+            sys.exit(1)
+        print("= = = De-tumbling the lab-frame vectors with the per-frame orientation quaternions.")
+        vecXHfit = []
+        for fn, lab in zip(args.qfile, vecXH):
+            _, q = plumedcolvario.read_qorient(fn)
+            if q.shape[0] != lab.shape[0]:
+                print("= = = ERROR: %s holds %i frames, the trajectory %i!" % (fn, q.shape[0], lab.shape[0]), file=sys.stderr)
+                sys.exit(1)
+            vecXHfit.append(hostct.detumble_vectors(lab, q))
     if tau_memory is not None and deltaT > 0.5 * tau_memory:
         print("= = = ERROR: delta-t form the trajectory is too small relative to tau! %g vs. %g" % (deltaT, tau_memory), file=sys.stderr)
         sys.exit(1)

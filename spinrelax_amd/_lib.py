@@ -36,6 +36,7 @@ SIGNATURES = {
     'sr_timer_start': (c_int, [c_void_p]),
     'sr_timer_stop_ms': (c_int, [c_void_p, POINTER(c_float)]),
     'sr_pack_soa_f32_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64]),
+    'sr_pack_soa_rot_f32_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64]),
     'sr_ct_psum_stride': (c_int64, [c_int64]),
     'sr_ct_max_frames_per_chunk': (c_int64, [c_void_p]),
     'sr_ct_palmer_f32_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int,
@@ -47,6 +48,7 @@ SIGNATURES = {
     'sr_rotate_hist_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int,
                                    c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64]),
     'sr_rotate_vectors_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    'sr_rotate_vectors_perframe_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     'sr_expfit_resjac_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_void_p, c_void_p]),
     'sr_expfit_lm_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_double,

@@ -106,6 +106,50 @@ __global__ __launch_bounds__(256) void k_pack_soa(const float *__restrict__ vecs
     }
 }
 
+// The same transposition with the de-tumbling folded in: every frame's vectors are rotated by that frame's unit
+// quaternion (float64, rotate_vector_simd's operation order, transforms3d_supplement.py:270-296) and rounded to the
+// float32 the planes hold.  SURVEY.md section 8(f)-1: lab-frame vectors + colvar-qorient in, body-frame C(t) out.
+__global__ __launch_bounds__(256) void k_pack_soa_rot(const float *__restrict__ vecs, int64_t N, int64_t Vtot, int64_t v0,
+                                                      int64_t nV, const double *__restrict__ quat,
+                                                      float *__restrict__ soa, int64_t Npad)
+{
+#pragma clang fp contract(off)
+    __shared__ float tile[kPackVecs * 3][kPackFrames + 1];
+    const int64_t n0 = (int64_t)blockIdx.x * kPackFrames;
+    const int64_t vb = (int64_t)blockIdx.y * kPackVecs;
+    const int nvec = (int)min((int64_t)kPackVecs, nV - vb);
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < kPackFrames * nvec; idx += 256) {
+        const int n = idx / nvec, k = idx - n * nvec;
+        const int64_t fr = n0 + n;
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        if (fr < N) {
+            const float *p = vecs + (fr * Vtot + v0 + vb + k) * 3;
+            const double vx = (double)p[0], vy = (double)p[1], vz = (double)p[2];
+            const double qw = quat[fr * 4 + 0], qx = quat[fr * 4 + 1], qy = quat[fr * 4 + 2], qz = quat[fr * 4 + 3];
+            const double ax = (qy * vz - qz * vy) + qw * vx;
+            const double ay = (qz * vx - qx * vz) + qw * vy;
+            const double az = (qx * vy - qy * vx) + qw * vz;
+            const double bx = qy * az - qz * ay;
+            const double by = qz * ax - qx * az;
+            const double bz = qx * ay - qy * ax;
+            ox = (float)((bx + bx) + vx);
+            oy = (float)((by + by) + vy);
+            oz = (float)((bz + bz) + vz);
+        }
+        tile[k * 3 + 0][n] = ox;
+        tile[k * 3 + 1][n] = oy;
+        tile[k * 3 + 2][n] = oz;
+    }
+    __syncthreads();
+    const int row = nvec * 3;
+    for (int idx = tid; idx < kPackFrames * row; idx += 256) {
+        const int k = idx / kPackFrames, n = idx - k * kPackFrames;
+        const int64_t fr = n0 + n;
+        if (fr < Npad) soa[(vb * 3 + k) * Npad + fr] = tile[k][n];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // kernel 1
 // ------------------------------------------------------------------------------------------
@@ -344,6 +388,25 @@ int sr_pack_soa_f32_dev(sr_ctx *ctx, const float *vecs, int64_t N, int64_t Vtot,
     SR_REQUIRE(gy <= 65535, -3, "sr_pack_soa_f32_dev: too many vectors in one call (%lld)", (long long)nV);
     hipLaunchKernelGGL(k_pack_soa, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ctx->stream, vecs, N, Vtot, v0, nV,
                        soa, Npad);
+    SR_HIP(hipGetLastError());
+    return 0;
+}
+
+int sr_pack_soa_rot_f32_dev(sr_ctx *ctx, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
+                            const double *quat, float *soa, int64_t Npad)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(vecs && soa && quat, -2, "sr_pack_soa_rot_f32_dev: null pointer");
+    SR_REQUIRE(N > 0 && Vtot > 0 && nV > 0 && v0 >= 0 && v0 + nV <= Vtot, -3,
+               "sr_pack_soa_rot_f32_dev: bad shape N=%lld Vtot=%lld v0=%lld nV=%lld", (long long)N, (long long)Vtot,
+               (long long)v0, (long long)nV);
+    SR_REQUIRE(Npad >= N && Npad % 4 == 0, -3, "sr_pack_soa_rot_f32_dev: Npad=%lld must be >= N and a multiple of 4",
+               (long long)Npad);
+    const int64_t gx = (Npad + kPackFrames - 1) / kPackFrames;
+    const int64_t gy = (nV + kPackVecs - 1) / kPackVecs;
+    SR_REQUIRE(gy <= 65535, -3, "sr_pack_soa_rot_f32_dev: too many vectors in one call (%lld)", (long long)nV);
+    hipLaunchKernelGGL(k_pack_soa_rot, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ctx->stream, vecs, N, Vtot, v0, nV,
+                       quat, soa, Npad);
     SR_HIP(hipGetLastError());
     return 0;
 }

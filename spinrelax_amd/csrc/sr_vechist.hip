@@ -221,15 +221,20 @@ __global__ __launch_bounds__(256) void k_vechist_finalize(const unsigned int *__
 }
 
 // rotated vectors themselves: (N, Vtot, 3) float32 slice -> (N, nV, 3) float64
+// quat != null: one unit quaternion per frame, (N, 4) as w x y z -- rotate_vector_simd with q of shape (N, 1, 4)
 __global__ __launch_bounds__(256) void k_rotate_vectors(const float *__restrict__ vecs, int64_t N, int64_t Vtot,
                                                         int64_t v0, int64_t nV, int rotate, double qw, double qx,
-                                                        double qy, double qz, double *__restrict__ out)
+                                                        double qy, double qz, const double *__restrict__ quat,
+                                                        double *__restrict__ out)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= N * nV) return;
     const int64_t n = idx / nV, v = idx - n * nV;
     const float *s = vecs + (n * Vtot + v0 + v) * 3;
     double x = (double)s[0], y = (double)s[1], z = (double)s[2];
+    if (quat) {
+        qw = quat[n * 4 + 0]; qx = quat[n * 4 + 1]; qy = quat[n * 4 + 2]; qz = quat[n * 4 + 3];
+    }
     if (rotate) {
         double rx, ry, rz;
         rotate_q(qw, qx, qy, qz, x, y, z, rx, ry, rz);
@@ -362,7 +367,30 @@ int sr_rotate_vectors_f32(sr_ctx *ctx, const float *vecs, int64_t N, int64_t Vto
     SR_HIP(hipMemcpyAsync(dvecs, vecs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     const int64_t tot = N * nV;
     hipLaunchKernelGGL(k_rotate_vectors, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, dvecs, N, Vtot, v0,
-                       nV, q ? 1 : 0, qn[0], qn[1], qn[2], qn[3], dout);
+                       nV, q ? 1 : 0, qn[0], qn[1], qn[2], qn[3], (const double *)nullptr, dout);
+    SR_HIP(hipGetLastError());
+    SR_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sr_rotate_vectors_perframe_f32(sr_ctx *ctx, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
+                                   const double *quat, double *out)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(vecs && out && quat, -2, "sr_rotate_vectors_perframe_f32: null pointer");
+    SR_REQUIRE(N > 0 && Vtot > 0 && nV > 0 && v0 >= 0 && v0 + nV <= Vtot, -3, "sr_rotate_vectors_perframe_f32: bad shape");
+    const size_t in_bytes = (size_t)N * Vtot * 3 * sizeof(float);
+    const size_t out_bytes = (size_t)N * nV * 3 * sizeof(double);
+    float *dvecs = (float *)sr_workspace(ctx, SR_WS_VECS, in_bytes);
+    double *dout = (double *)sr_workspace(ctx, SR_WS_OUT0, out_bytes);
+    double *dq = (double *)sr_workspace(ctx, SR_WS_IN0, (size_t)N * 4 * sizeof(double));
+    if (!dvecs || !dout || !dq) return -5;
+    SR_HIP(hipMemcpyAsync(dvecs, vecs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    SR_HIP(hipMemcpyAsync(dq, quat, (size_t)N * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const int64_t tot = N * nV;
+    hipLaunchKernelGGL(k_rotate_vectors, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, dvecs, N, Vtot, v0,
+                       nV, 1, 1.0, 0.0, 0.0, 0.0, (const double *)dq, dout);
     SR_HIP(hipGetLastError());
     SR_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     SR_HIP(hipStreamSynchronize(ctx->stream));

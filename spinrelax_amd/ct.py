@@ -122,9 +122,35 @@ def S2_from_outer_sums(outer, frames_per_block, blocked=True):
         return np.stack((np.mean(s, axis=0), np.std(s, axis=0) / (np.sqrt(nBlocks) - 1.0)), axis=-1)
 
 
+def vecnorm_NDarray(v, axis=-1):
+    """transforms3d_supplement.py:40-52: normalise along an axis, 0/0 -> 0."""
+    v = np.asarray(v)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return np.nan_to_num(v / np.linalg.norm(v, axis=axis, keepdims=True))
+
+
 def rotate_vector_simd(v, q, ctx=None):
-    """transforms3d_supplement.py:270-296 for v (N, V, 3) float32 and one quaternion q (4,): float64 result."""
+    """transforms3d_supplement.py:270-296 for v (N, V, 3) float32 and either one quaternion q (4,) or one per
+    frame, q (N, 4) / (N, 1, 4) (numpy broadcasting over the vector axis): float64 result, rotation on the GPU."""
     v = np.ascontiguousarray(v, dtype=np.float32)
     shp = v.shape
+    q = np.asarray(q, dtype=np.float64)
+    if q.ndim == 3 and q.shape[1] == 1:
+        q = q[:, 0, :]
+    if q.ndim == 2:
+        q = vecnorm_NDarray(q)
     out = _ctx(ctx).rotate_vectors(v.reshape(-1, 1, 3) if v.ndim == 2 else v, q)
     return out.reshape(shp)
+
+
+def detumble_vectors(vecs_lab, q_orient, ctx=None):
+    """Body-frame vectors from lab-frame vectors and the orientation trajectory q_orient(t) (PLUMED colvar-qorient,
+    float32 fields, plumedcolvario.py:24-81): v_body(t) = R(q(t))^-1 v_lab(t), i.e. rotate_vector_simd with the
+    conjugate quaternion per frame.  Returns float32 like the vectors the superposition route produces
+    (calculate-Ct-from-traj.py:64-86, 466-467)."""
+    q = np.array(q_orient, dtype=np.float64)
+    if q.ndim != 2 or q.shape[1] != 4 or q.shape[0] != np.shape(vecs_lab)[0]:
+        raise ValueError('detumble_vectors: need one quaternion (w x y z) per frame, got %s for %d frames'
+                         % (q.shape, np.shape(vecs_lab)[0]))
+    q[:, 1:] *= -1.0
+    return rotate_vector_simd(vecs_lab, q, ctx=ctx).astype(np.float32)

@@ -115,6 +115,9 @@ class Context:
     def pack_soa_dev(self, vecs_ptr, N, Vtot, v0, nV, soa_ptr, Npad):
         check(self.lib.sr_pack_soa_f32_dev(self.h, vecs_ptr, N, Vtot, v0, nV, soa_ptr, Npad), 'sr_pack_soa_f32_dev')
 
+    def pack_soa_rot_dev(self, vecs_ptr, N, Vtot, v0, nV, quat_ptr, soa_ptr, Npad):
+        check(self.lib.sr_pack_soa_rot_f32_dev(self.h, vecs_ptr, N, Vtot, v0, nV, quat_ptr, soa_ptr, Npad), 'sr_pack_soa_rot_f32_dev')
+
     def ct_palmer_dev(self, soa_ptr, Npad, R, F, nV, Ct_ptr, dCt_ptr, chunk_start=None, mode=0, psum_ptr=None):
         cs = None if chunk_start is None else np.ascontiguousarray(chunk_start, dtype=np.int64)
         check(self.lib.sr_ct_palmer_f32_dev(self.h, soa_ptr, Npad, R, F, nV, _ptr(cs), int(mode), psum_ptr, Ct_ptr, dCt_ptr),
@@ -151,11 +154,18 @@ class Context:
               'sr_rotate_hist_f32_dev')
 
     def rotate_vectors(self, vecs, q, v0=0, nV=None):
+        """q: (4,) one rotation for everything, or (N, 4) one UNIT quaternion per frame."""
         vecs = _f32(vecs)
         N, Vtot, _ = vecs.shape
         nV = Vtot - v0 if nV is None else nV
         out = np.empty((N, nV, 3))
         qq = None if q is None else _f64(q)
+        if qq is not None and qq.ndim == 2:
+            if qq.shape != (N, 4):
+                raise ValueError('per-frame quaternions must have shape (frames, 4)')
+            check(self.lib.sr_rotate_vectors_perframe_f32(self.h, _ptr(vecs), N, Vtot, v0, nV, _ptr(qq), _ptr(out)),
+                  'sr_rotate_vectors_perframe_f32')
+            return out
         check(self.lib.sr_rotate_vectors_f32(self.h, _ptr(vecs), N, Vtot, v0, nV, _ptr(qq), _ptr(out)), 'sr_rotate_vectors_f32')
         return out
 

@@ -94,7 +94,7 @@ class _Slot:
 class DevicePipeline:
     def __init__(self, ctx, device, frames, V, R, F, dt, q_rot=None, Diso=None, aniso=None, field_MHz=(600.133,),
                  zeta=0.890023, histBinX=72, listDoG=(2, 3, 5, 7, 9), csa=None, depth=1, stream=None, reserve_cus=0,
-                 fits_on_reserved_only=False, chiSqThreshold=0.5):
+                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None):
         self.ctx = ctx
         self.dev = device
         self.frames, self.V, self.R, self.F, self.dt = frames, V, R, F, dt
@@ -140,6 +140,14 @@ class DevicePipeline:
         self.tau_guess = torch.from_numpy(fitCt.tau_guesses(t, self.listDoG)).to(device)
         self.binvecs = hm.lambert_bin_vectors(self.edges)
         self.binvecs_dev = torch.from_numpy(np.ascontiguousarray(self.binvecs, dtype=np.float64)).to(device)
+        # per-frame de-tumbling: lab-frame vectors in, rotated by conj(q_orient(t)) inside the pack
+        self.quat_dev = None
+        if q_orient is not None:
+            qc = np.array(q_orient, dtype=np.float64)
+            if qc.shape != (frames, 4):
+                raise ValueError('q_orient must hold one quaternion (w x y z) per frame: (%d, 4)' % frames)
+            qc[:, 1:] *= -1.0
+            self.quat_dev = torch.from_numpy(np.ascontiguousarray(hostct.vecnorm_NDarray(qc))).to(device)
         self.csa = csa
         self._packed = False
         self.nfev_total = 0
@@ -196,7 +204,11 @@ class DevicePipeline:
 
     # ---- stages (each enqueues on the context's current stream) ----
     def stage_pack(self, vecs):
-        self.ctx.pack_soa_dev(vecs.data_ptr(), self.frames, vecs.shape[1], 0, self.V, self.soa.data_ptr(), self.Npad)
+        if self.quat_dev is not None:
+            self.ctx.pack_soa_rot_dev(vecs.data_ptr(), self.frames, vecs.shape[1], 0, self.V, self.quat_dev.data_ptr(),
+                                      self.soa.data_ptr(), self.Npad)
+        else:
+            self.ctx.pack_soa_dev(vecs.data_ptr(), self.frames, vecs.shape[1], 0, self.V, self.soa.data_ptr(), self.Npad)
 
     def stage_ct(self, s=None):
         s = s or self.slots[0]

@@ -195,3 +195,31 @@ def test_shard_ranges_cover_everything():
             assert cover == list(range(V))
             sizes = srdist.shard_sizes(V, world)
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_plumed_colvar_reader_equals_reference_reader(capsys):
+    """spinrelax_amd.plumedcolvario against what the reference's plumedcolvario.read_from_plumedprint returned for the
+    same file (tests/golden/cfg1_colvar-qorient, oracle/gen_golden_detumble.py)."""
+    from spinrelax_amd import plumedcolvario
+    g = golden('cfg1_detumble.npz')
+    names, data = plumedcolvario.read_from_plumedprint(os.path.join(GOLD, 'cfg1_colvar-qorient'))
+    assert names == list(g['field_names'])
+    assert data.dtype == np.float32 and data.flags['F_CONTIGUOUS']
+    np.testing.assert_array_equal(data, g['colvar'])
+    t, q = plumedcolvario.read_qorient(os.path.join(GOLD, 'cfg1_colvar-qorient'))
+    np.testing.assert_array_equal(q, g['q32'])
+    np.testing.assert_array_equal(t, g['colvar'][0])
+    out = capsys.readouterr().out
+    assert 'Found 1000 data-like lines' in out and "'time', 'q.w', 'q.x', 'q.y', 'q.z', 'rest0.bias'" in out
+
+
+def test_plumed_colvar_reader_rejects_malformed(tmp_path):
+    from spinrelax_amd import plumedcolvario
+    bad = tmp_path / 'bad'
+    bad.write_text(' 0.0 1.0 0.0 0.0 0.0\n')
+    assert plumedcolvario.read_from_plumedprint(str(bad)) == -1
+    bad.write_text('#! FIELDS time q.w q.x\n 0.0 1.0\n')
+    assert plumedcolvario.read_from_plumedprint(str(bad)) == -1
+    bad.write_text('#! FIELDS time a b\n 0.0 1.0 2.0\n')
+    with pytest.raises(ValueError):
+        plumedcolvario.read_qorient(str(bad))

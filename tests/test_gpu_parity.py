@@ -476,3 +476,40 @@ def test_device_order_search_edge_cases(ctx):
         assert dev['best'][2] == -1 and dev['K'][2] == 0
         S2h, Ch, tauh, Kh, chih = search.selected_arrays(Kmax=2)
         assert np.array_equal(dev['S2'], S2h) and np.array_equal(dev['C'], Ch) and np.array_equal(dev['tau'], tauh)
+
+
+def test_per_frame_rotation_and_fused_detumbling(ctx):
+    """SURVEY.md section 8(f)-1.  (a) sr_rotate_vectors_perframe_f32 against the reference's rotate_vector_simd run bond
+    by bond with one quaternion per frame; (b) the de-tumbling folded into the pack kernel
+    (sr_pack_soa_rot_f32_dev) followed by the C(t) kernel against the reference's C(t) of the de-tumbled vectors."""
+    import torch
+    from spinrelax_amd import ct as hostct
+    g = golden('cfg1_detumble.npz')
+    lab = g['lab']
+    qinv = g['q32'].astype(np.float64)
+    qinv[:, 1:] *= -1.0
+    rot = hostct.rotate_vector_simd(lab, qinv[:, None, :], ctx=ctx)
+    assert rot.dtype == np.float64
+    assert np.max(np.abs(rot[:, :8] - g['body64'])) <= 2.3e-16          # one ulp of a unit vector component
+    body32 = hostct.detumble_vectors(lab, g['q32'], ctx=ctx)
+    assert body32.dtype == np.float32 and np.array_equal(body32, rot.astype(np.float32))
+    with pytest.raises(ValueError):
+        hostct.detumble_vectors(lab, g['q32'][:10], ctx=ctx)
+    # fused: planes straight from the lab-frame vectors + quaternions in HBM
+    s = dict(R=10, F=100, L=50)
+    N, V = lab.shape[:2]
+    dev = torch.device('cuda', 0)
+    dlab = torch.from_numpy(lab).to(dev)
+    dq = torch.from_numpy(hostct.vecnorm_NDarray(qinv)).to(dev)
+    Npad = (N + 63) // 64 * 64
+    soa = torch.zeros((V, 3, Npad), device=dev, dtype=torch.float32)
+    Ct = torch.empty((s['L'], V), device=dev, dtype=torch.float64)
+    dCt = torch.empty_like(Ct)
+    ctx.set_stream(0)
+    ctx.pack_soa_rot_dev(dlab.data_ptr(), N, V, 0, V, dq.data_ptr(), soa.data_ptr(), Npad)
+    ctx.ct_palmer_dev(soa.data_ptr(), Npad, s['R'], s['F'], V, Ct.data_ptr(), dCt.data_ptr())
+    torch.cuda.synchronize()
+    planes = soa.cpu().numpy()[:, :, :N]
+    assert np.array_equal(np.transpose(planes, (2, 0, 1)), body32)
+    assert relerr(Ct.cpu().numpy(), g['Ct64']) < 1e-12
+    assert np.allclose(dCt.cpu().numpy(), g['dCt64'], rtol=1e-9, atol=1e-15)

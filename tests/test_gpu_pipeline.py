@@ -97,3 +97,29 @@ def test_pipeline_batches_in_flight_are_identical_and_ordered(setup, depth, rese
         assert np.array_equal(best, want_best)
     assert len({c for *_, c in seen}) == 1
     pipe.close()
+
+
+def test_pipeline_with_orientation_trajectory(setup):
+    """Lab-frame vectors + per-frame orientation quaternions through the pipeline (de-tumbling folded into the pack
+    kernel) == the pipeline fed the de-tumbled vectors."""
+    from conftest import golden
+    from spinrelax_amd import ct as hostct
+    from spinrelax_amd.pipeline import DevicePipeline
+    st = setup
+    g = golden('cfg1_detumble.npz')
+    s, synth, torch = st['s'], st['synth'], st['torch']
+    kw = dict(q_rot=synth.Q_EXT, Diso=synth.DISO, aniso=synth.DANI, field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA, depth=1)
+    lab = torch.from_numpy(g['lab']).to(st['dev'])
+    p1 = DevicePipeline(st['ctx'], st['dev'], s['frames'], 32, s['R'], s['F'], s['dt'], q_orient=g['q32'],
+                        stream=torch.cuda.Stream(device=st['dev']), **kw)
+    out1 = p1.step(lab).copy()
+    Ct1 = p1.Ct.cpu().numpy()
+    body = torch.from_numpy(hostct.detumble_vectors(g['lab'], g['q32'], ctx=st['ctx'])).to(st['dev'])
+    p2 = DevicePipeline(st['ctx'], st['dev'], s['frames'], 32, s['R'], s['F'], s['dt'],
+                        stream=torch.cuda.Stream(device=st['dev']), **kw)
+    out2 = p2.step(body).copy()
+    assert np.array_equal(Ct1, p2.Ct.cpu().numpy())
+    assert np.max(np.abs(Ct1 / g['Ct64'] - 1)) < 1e-12
+    assert np.array_equal(out1, out2, equal_nan=True)
+    with pytest.raises(ValueError):
+        DevicePipeline(st['ctx'], st['dev'], s['frames'], 32, s['R'], s['F'], s['dt'], q_orient=g['q32'][:5], **kw)

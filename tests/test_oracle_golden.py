@@ -240,3 +240,20 @@ def test_oracle_pinned_against_live_reference_when_present(synth_cache):
     np.testing.assert_array_equal(dCo, dCr)
     q = np.array([0.3, -0.5, 0.1, 0.8])
     np.testing.assert_array_equal(o.rotate_vector_simd(v, q), ref.qs.rotate_vector_simd(v, q))
+
+
+def test_oracle_per_frame_rotation_equals_reference():
+    """rotate_vector_simd with one quaternion per frame: the oracle's broadcast form against
+    the reference run bond by bond (the only N-D form the reference's own broadcasting supports)."""
+    g = golden('cfg1_detumble.npz')
+    qinv = g['q32'].astype(np.float64)
+    qinv[:, 1:] *= -1.0
+    back = o.rotate_vector_simd(g['lab'][:, :8], qinv[:, None, :])
+    assert back.dtype == np.float64
+    np.testing.assert_array_equal(back, g['body64'])
+    s = dict(dt=10.0, tau=1000.0)
+    full = o.rotate_vector_simd(g['lab'], qinv[:, None, :]).astype(np.float32)
+    v4 = o.reformat_vecs_by_tau([full], s['dt'], s['tau'])
+    Ct, dCt = o.calculate_Ct_Palmer(v4.astype(np.float64))
+    np.testing.assert_array_equal(Ct, g['Ct64'])
+    np.testing.assert_array_equal(dCt, g['dCt64'])

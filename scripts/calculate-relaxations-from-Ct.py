@@ -7,7 +7,8 @@ the field, and writes `<o>_R1.dat`, `<o>_R2.dat`, `<o>_NOE.dat`, `<o>_rho.dat` (
 and frequencies are evaluated in one batched GPU launch (sr_jomega_relax_f64).
 
 The legacy single-field optimisation modes (--opt Diso|DisoS2|DisoCSA|DisoS2CSA|new; marked deprecated in
-the reference's README.md:106) are not part of this build: SURVEY.md section 8(f)-4.
+the reference's README.md:106) run scipy's Powell search on the host with every
+objective evaluation being one launch of the same kernel (spinrelax_amd/legacy_opt.py).
 """
 import argparse
 import os
@@ -65,9 +66,10 @@ def build_parser():
     p.add_argument('--rXH', type=float, default=np.nan)
     p.add_argument('--zeta', type=float, default=0.890023, help='Zero-point vibration scaling of all C(t) amplitudes.')
     p.add_argument('--csa', type=str, default=None, help='CSA value, or a file of per-residue CSA values.')
-    p.add_argument('--opt', '--fit', type=str, default=None, help='Legacy single-field optimisation (not available in this build).')
-    p.add_argument('--cycles', type=int, default=100)
-    p.add_argument('--tol', type=float, default=1e-6)
+    p.add_argument('--opt', '--fit', type=str, default=None,
+                   help='Legacy single-field optimisation against --expfn: Diso, DisoS2, DisoCSA, DisoS2CSA or new (global Diso + per-residue CSA).')
+    p.add_argument('--cycles', type=int, default=100, help='Maximum refinement cycles of --opt new.')
+    p.add_argument('--tol', type=float, default=1e-6, help='Relative tolerance that ends the refinement cycles of --opt new.')
     p.add_argument('--theoretical', dest='bTheoretical', action='store_true',
                    help='Print the rigid-body relaxation (S2 = zeta, no internal motion) and exit.')
     return p
@@ -81,8 +83,9 @@ def main():
         if args.expfn is None:
             print("= = = ERROR: Cannot conduct optimisation without a target experimental scattering file! (Missing --expfn )", file=sys.stderr)
             sys.exit(1)
-        print("= = = ERROR: the legacy --opt modes are not part of the GPU build; use calculate-relaxations-multi-field.py.", file=sys.stderr)
-        sys.exit(1)
+        if args.opt not in ('new', 'Diso', 'DisoS2', 'DisoCSA', 'DisoS2CSA'):
+            print("= = Invalid optimisation mode!", file=sys.stderr)
+            sys.exit(1)
     zeta = args.zeta
     if zeta != 1.0:
         print(" = = Applying scaling of all C(t) magnitudes to account for zero-point QM vibrations (zeta) of %g" % zeta)
@@ -210,15 +213,30 @@ def main():
         S2_list[i] *= zeta
         consts_list[i] *= zeta
 
-    if args.Jomega:
-        datablock = sd._obtain_Jomega(relax_obj, num_vecs, S2_list, consts_list, taus_list, vecXH, weights=vecXHweights)
+    param_names = ("Diso", "zeta", "CSA", "chi")
+    param_scaling = (1.0, zeta, 1.0e6, 1.0)
+    param_units = (relax_obj.timeUnit + "^-1", "a.u.", "ppm", "a.u.")
+    if args.opt is None:
+        if args.Jomega:
+            datablock = sd._obtain_Jomega(relax_obj, num_vecs, S2_list, consts_list, taus_list, vecXH, weights=vecXHweights)
+        else:
+            datablock = sd._obtain_R1R2NOErho(relax_obj, num_vecs, S2_list, consts_list, taus_list, vecXH, weights=vecXHweights,
+                                              CSAvaluesArray=CSAvaluesArray)
+        optHeader = print_fitting_params_headers(names=param_names,
+                                                 values=np.multiply(param_scaling, (Diso, 1.0, relax_obj.gX.csa, 0.0)),
+                                                 units=param_units, bFit=(False, False, False, False))
     else:
+        # Section 2 of the reference (:775-1004): minimisation against experimental data, legacy single-field modes
+        from spinrelax_amd import legacy_opt
+        print("= = = Reading Experimental relaxation parameter files")
+        exp_resid, expblock = legacy_opt.read_experiment(args.expfn, relax_obj.rotdifModel.name, gs.load_xys)
+        matched = legacy_opt.match_residues(sim_resid, [int(x) for x in exp_resid], expblock, S2_list, consts_list, taus_list,
+                                            vecXH, vecXHweights, CSAvaluesArray)
+        optHeader, CSAvaluesArray, S2_list = legacy_opt.run(
+            args.opt, relax_obj, Diso, matched, None, args.cycles, args.tol, out_pref, print_fitting_params_headers,
+            param_names, param_scaling, param_units, gs.print_xy, sim_resid, CSAvaluesArray, S2_list)
         datablock = sd._obtain_R1R2NOErho(relax_obj, num_vecs, S2_list, consts_list, taus_list, vecXH, weights=vecXHweights,
                                           CSAvaluesArray=CSAvaluesArray)
-    optHeader = print_fitting_params_headers(names=("Diso", "zeta", "CSA", "chi"),
-                                             values=np.multiply((1.0, zeta, 1.0e6, 1.0), (Diso, 1.0, relax_obj.gX.csa, 0.0)),
-                                             units=(relax_obj.timeUnit + "^-1", "a.u.", "ppm", "a.u."),
-                                             bFit=(False, False, False, False))
     print(" = = Completed Relaxation calculations.")
 
     if args.Jomega:

@@ -161,8 +161,11 @@ struct CtArgs {
     int R, F, Fp, L, Lp, nslab, mode;
 };
 
+#ifndef SR_CT_WAVES_EU
+#define SR_CT_WAVES_EU 3
+#endif
 template <int W>
-__global__ __launch_bounds__(W * 64) void k_ct_palmer(CtArgs a)
+__global__ __launch_bounds__(W * 64, SR_CT_WAVES_EU) void k_ct_palmer(CtArgs a)
 {
     extern __shared__ __align__(16) float lds[];
     // This is the throughput kernel of the pipeline; the fit wavefronts of the previous batch share its SIMDs.  Raised

@@ -331,6 +331,13 @@ class DevicePipeline:
                     on_finished(s)
         self.ctx.set_stream(self.main.cuda_stream)
 
+    def prime(self, vecs):
+        """Set-up: push one batch through every slot so that code objects are loaded, the slots' device and pinned
+        buffers are resident and every stream has seen a launch before the first batch that counts."""
+        self.run(vecs, self.depth)
+        torch.cuda.synchronize(self.dev)
+        self.nfev_total = 0
+
     def step(self, vecs):
         """One batch from vectors to R1/R2/NOE; returns the (E, V, 4, 2) table."""
         self.front(vecs, 0)

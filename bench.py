@@ -32,8 +32,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # one hardware queue per in-flight batch (their fit stragglers run ~25 ms each) + the C(t) stream; the HIP runtime
-# multiplexes streams onto 4 queues by default and streams that share a queue serialise (spinrelax_amd/pipeline.py)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+# multiplexes streams onto 4 queues by default and streams that share a queue serialise (spinrelax_amd/pipeline.py).
+# Not more than needed: two processes with 16 queues each on ONE GPU oversubscribe the hardware queues and the
+# scheduler's time-slicing makes a step 20x slower (seen in the 2-rank rehearsal on one device).
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector = FP32 matrix peak
 PEAK_HBM_GBS = 8000.0

@@ -168,15 +168,30 @@ def main():
 
     with torch.cuda.stream(stream):
 
+        # Result exchange: every rank ends up with C(t), dC(t), the histogram and the R1/R2/NOE
+        # table of all vectors.  The all-gathers of a finished batch run on their own stream, beside the C(t) launches
+        # the host has already queued for the following batches; the main stream only waits for them before it
+        # reuses that batch's buffers (depth batches later).
+        gstream = torch.cuda.Stream(device=dev) if world > 1 else None
+        gbuf = {}
+
         def gather_results(slot):
             if world == 1:
                 return
-            for tns in (slot.Ct, slot.dCt, slot.hist):
-                out = [torch.empty_like(tns) for _ in range(world)]
-                dist.all_gather(out, tns.contiguous())
-            r = torch.from_numpy(np.ascontiguousarray(slot.relax_out)).to(dev)
-            out = [torch.empty_like(r) for _ in range(world)]
-            dist.all_gather(out, r)
+            with torch.cuda.stream(gstream):
+                for name in ('Ct', 'dCt', 'hist'):
+                    tns = getattr(slot, name)
+                    key = (id(slot), name)
+                    if key not in gbuf:
+                        gbuf[key] = [torch.empty_like(tns) for _ in range(world)]
+                    dist.all_gather(gbuf[key], tns)
+                key = (id(slot), 'relax')
+                if key not in gbuf:
+                    gbuf[key] = [torch.empty_like(slot.relax) for _ in range(world)]
+                dist.all_gather(gbuf[key], slot.relax)
+                ev = torch.cuda.Event()
+                ev.record(gstream)
+            pipe.main.wait_event(ev)
 
         def run_batches(nb, events=None):
             pipe.run(vecs, nb, events, on_finished=gather_results)

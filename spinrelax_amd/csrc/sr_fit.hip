@@ -53,6 +53,9 @@ __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 #ifndef SR_FIT_LEADER
 #define SR_FIT_LEADER 0
 #endif
+#ifndef SR_FIT_LF_LDS
+#define SR_FIT_LF_LDS 1      // Cholesky factor in a per-wave LDS area instead of 90 VGPRs
+#endif
 #ifndef SR_FIT_MARK
 #define SR_FIT_MARK 0
 #endif
@@ -230,12 +233,13 @@ __device__ __forceinline__ void phi_from_factor(const double *Lf, const double *
 
 // common.py:solve_lsq_trust_region
 template <int N>
-__device__ void solve_tr(const double *B, const double *g, int m, double Delta, double &alpha, double *p)
+__device__ void solve_tr(const double *B, const double *g, int m, double Delta, double &alpha, double *p, double *lfbuf)
 {
     // rank test of scipy: s_min > EPS*m*s_max on the singular values of the augmented Jacobian.  Here:
     // B is accepted as full rank when its Cholesky factorisation succeeds with pivots above the
     // equivalent threshold (EPS*m)^2 * max diag.
-    double Lf[N * (N + 1) / 2], inv[N], lmin2;
+    double Lf_regs[SR_FIT_LF_LDS ? 1 : N * (N + 1) / 2], inv[N], lmin2;
+    double *Lf = SR_FIT_LF_LDS ? lfbuf : Lf_regs;
     bool full_rank = cholN<N>(B, 0.0, Lf, inv, lmin2);
     if (full_rank) {
         double dmax = 0.0;
@@ -447,7 +451,7 @@ constexpr int kBcast = 16;
 constexpr int kMat = kNmax * (kNmax + 1) / 2;                        // one packed symmetric n x n matrix
 __host__ __device__ constexpr size_t fit_lds_doubles(int W, int64_t L_staged)
 {
-    return (size_t)W * kRedStride + kBcast + 2 * kMat + 3 * (size_t)L_staged;
+    return (size_t)W * kRedStride + kBcast + (2 + W) * kMat + 3 * (size_t)L_staged;
 }
 
 template <int W, bool LDS>
@@ -457,7 +461,8 @@ struct Residue {
     static constexpr int BC = W * kRedStride;          // kBcast doubles: leader wave -> workgroup broadcast
     static constexpr int MA = BC + kBcast;             // J^T J of the current point (packed), shared by all threads
     static constexpr int MB = MA + kMat;               // the scaled trust-region matrix B
-    static constexpr int RED = MB + kMat;              // start of the staged residue
+    static constexpr int LF = MB + kMat;               // one Cholesky factor per wave (every lane writes the same values)
+    static constexpr int RED = LF + W * kMat;          // start of the staged residue
 
     const double *tg, *yg, *wg;   // global (LDS == false)
     const double *sg;             // sigma of this residue (global) or null
@@ -470,6 +475,7 @@ struct Residue {
     // broadcast ds_read_b64 whose addresses are known up front.
     __device__ __forceinline__ double *matA() const { return fit_smem + MA; }
     __device__ __forceinline__ double *matB() const { return fit_smem + MB; }
+    __device__ __forceinline__ double *matLf() const { return fit_smem + LF + (tid >> 6) * kMat; }
     __device__ __forceinline__ double ld_t(int l) const { return LDS ? fit_smem[RED + l] : tg[l]; }
     __device__ __forceinline__ double ld_y(int l) const { return LDS ? fit_smem[RED + L + l] : yg[l]; }
     __device__ __forceinline__ double ld_w(int l) const { return LDS ? fit_smem[RED + 2 * L + l] : wg[l]; }
@@ -729,9 +735,9 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
                 if (term_set || nfev == max_nfev) break;
 
                 // The trust-region sub-problem (Cholesky per Levenberg parameter, reflective / Cauchy step selection) is
-                // a few thousand dependent float64 operations with no parallelism in it.  The leader wave solves it
-                // and broadcasts the trial point through LDS; the other waves wait at the barrier, which leaves their
-                // SIMDs to the C(t) wavefronts of the next batch that share the CU.
+                // a few thousand dependent float64 operations on workgroup-uniform data.  Everything long-lived in it
+                // (J^T J, B, the Cholesky factor) lives in LDS, not in VGPRs; moving d and g_h there as well did not pay.
+                // (SR_FIT_LEADER=1: only the leader wave solves it and broadcasts the trial point.)
                 double d[N], g_h[N];
                 const double theta = fmax(0.995, 1 - g_norm);
 #pragma unroll
@@ -751,7 +757,7 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
                     double predicted, step_h_norm, step_norm;
                     if (leader) {
                         double p_h[N], p[N], step[N], step_h[N];
-                        solve_tr<N>(B, g_h, m, Delta, alpha, p_h);
+                        solve_tr<N>(B, g_h, m, Delta, alpha, p_h, T.matLf());
 #pragma unroll
                         for (int i = 0; i < N; ++i) p[i] = d[i] * p_h[i];
                         select_step<N>(x, B, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h, predicted);
@@ -814,7 +820,8 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
     // ---- outputs: popt, pcov = (J^T J)^-1 * 2 cost / (m - n)  (curve_fit, _minpack_py.py:1040-1055), chi ----
     cov_ok = false;
     if (have_fit && m > N) {
-        double Lf[NT], inv[N], lmin2;
+        double Lf_regs[SR_FIT_LF_LDS ? 1 : NT], inv[N], lmin2;
+        double *Lf = SR_FIT_LF_LDS ? T.matLf() : Lf_regs;
         cov_ok = cholN<N>(A, 0.0, Lf, inv, lmin2);
         if (cov_ok) {
             // conditioning guard equivalent to scipy's singular-value cut eps*max(m,n)*s_max

@@ -82,6 +82,8 @@ __device__ __forceinline__ double wave_sum_f64(double v)
 constexpr int kPackFrames = 64;
 constexpr int kPackVecs = 32;
 
+// 16-byte accesses on both sides: a frame's 32 vectors are 96 consecutive floats (24 float4 when the row start is
+// 16-byte aligned, i.e. Vtot*3 and (v0+vb)*3 multiples of 4), a plane row of 64 frames is 16 float4.
 __global__ __launch_bounds__(256) void k_pack_soa(const float *__restrict__ vecs, int64_t N, int64_t Vtot,
                                                   int64_t v0, int64_t nV, float *__restrict__ soa, int64_t Npad)
 {
@@ -91,18 +93,37 @@ __global__ __launch_bounds__(256) void k_pack_soa(const float *__restrict__ vecs
     const int nvec = (int)min((int64_t)kPackVecs, nV - vb);
     const int row = nvec * 3;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < kPackFrames * row; idx += 256) {
-        const int n = idx / row, k = idx - n * row;
-        const int64_t fr = n0 + n;
-        float val = 0.f;
-        if (fr < N) val = vecs[(fr * Vtot + v0 + vb) * 3 + k];
-        tile[k][n] = val;
+    const bool vec4 = ((Vtot * 3) & 3) == 0 && (((v0 + vb) * 3) & 3) == 0 && (row & 3) == 0;
+    if (vec4) {
+        const int q4 = row >> 2;                              // float4 per frame
+        for (int idx = tid; idx < kPackFrames * q4; idx += 256) {
+            const int n = idx / q4, q = idx - n * q4;
+            const int64_t fr = n0 + n;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fr < N) val = *reinterpret_cast<const float4 *>(vecs + (fr * Vtot + v0 + vb) * 3 + 4 * q);
+            tile[4 * q + 0][n] = val.x;
+            tile[4 * q + 1][n] = val.y;
+            tile[4 * q + 2][n] = val.z;
+            tile[4 * q + 3][n] = val.w;
+        }
+    } else {
+        for (int idx = tid; idx < kPackFrames * row; idx += 256) {
+            const int n = idx / row, k = idx - n * row;
+            const int64_t fr = n0 + n;
+            float val = 0.f;
+            if (fr < N) val = vecs[(fr * Vtot + v0 + vb) * 3 + k];
+            tile[k][n] = val;
+        }
     }
     __syncthreads();
-    for (int idx = tid; idx < kPackFrames * row; idx += 256) {
-        const int k = idx / kPackFrames, n = idx - k * kPackFrames;
+    // Npad % 4 == 0 and n0 % 64 == 0: every group of four frames is either fully inside the planes or fully outside
+    for (int idx = tid; idx < (kPackFrames / 4) * row; idx += 256) {
+        const int k = idx / (kPackFrames / 4), n = (idx - k * (kPackFrames / 4)) * 4;
         const int64_t fr = n0 + n;
-        if (fr < Npad) soa[(vb * 3 + k) * Npad + fr] = tile[k][n];
+        if (fr < Npad) {
+            const float4 o = make_float4(tile[k][n], tile[k][n + 1], tile[k][n + 2], tile[k][n + 3]);
+            *reinterpret_cast<float4 *>(soa + (vb * 3 + k) * Npad + fr) = o;
+        }
     }
 }
 

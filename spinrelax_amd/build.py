@@ -14,9 +14,11 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 # sr_ct.hip: the SLP vectoriser packs the FMAs of the C(t) inner loop into v_pk_fma_f32, whose operand pairs then
 # need ~1 v_mov per FMA (rocprofv3: 4.8e9 VALU instructions for 2.5e9 FMAs); plain v_fma_f32 issues at the same rate.
-EXTRA = {'sr_ct.hip': ['-fno-slp-vectorize']}
+EXTRA = {'sr_ct.hip': ['-fno-slp-vectorize'],
+         # sr_fit.hip: explicit fma() only, see the note at the top of the file
+         'sr_fit.hip': ['-ffp-contract=off']}
 if os.environ.get('SR_FIT_DEV_FAST'):          # development: only the order-search variants the benchmark uses
-    EXTRA['sr_fit.hip'] = ['-DSR_FIT_DEV_FAST']
+    EXTRA['sr_fit.hip'] = EXTRA['sr_fit.hip'] + ['-DSR_FIT_DEV_FAST']
 
 
 def _stale(target, deps):

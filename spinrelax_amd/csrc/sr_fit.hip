@@ -22,6 +22,10 @@
 // every thread and held in registers (the kernel is templated on n so every small array is statically
 // indexed).  The critical path of a fit is serial (up to 100 n dependent iterations), so the kernel is
 // latency-bound by design: the W waves exist to shorten each iteration, not to raise throughput.
+// Floating-point contraction is OFF for this file (spinrelax_amd/build.py): every fused multiply-add is written as
+// fma(), so k_trf<n> and the search_order<n> instances of k_order_search -- separately compiled copies of the same
+// solver -- round identically whatever the optimiser does around them (with -ffp-contract=fast the two differed in
+// the last bit of a few sums, enough to send an ill-conditioned nine-parameter fit down another path).
 #include "sr_internal.h"
 
 namespace {
@@ -126,7 +130,7 @@ __device__ __forceinline__ double dotN(const double *a, const double *b)
 {
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < N; ++i) s += a[i] * b[i];
+    for (int i = 0; i < N; ++i) s = fma(a[i], b[i], s);
     return s;
 }
 template <int N>
@@ -141,8 +145,8 @@ __device__ __forceinline__ double quadN(const double *B, const double *s)
     for (int i = 0; i < N; ++i) {
         double r = 0.0;
 #pragma unroll
-        for (int j = 0; j < N; ++j) r += B[tri(i, j)] * s[j];
-        q += s[i] * r;
+        for (int j = 0; j < N; ++j) r = fma(B[tri(i, j)], s[j], r);
+        q = fma(s[i], r, q);
     }
     return q;
 }
@@ -155,8 +159,8 @@ __device__ __forceinline__ double bilinN(const double *B, const double *u, const
     for (int i = 0; i < N; ++i) {
         double r = 0.0;
 #pragma unroll
-        for (int j = 0; j < N; ++j) r += B[tri(i, j)] * s[j];
-        q += u[i] * r;
+        for (int j = 0; j < N; ++j) r = fma(B[tri(i, j)], s[j], r);
+        q = fma(u[i], r, q);
     }
     return q;
 }
@@ -176,7 +180,7 @@ __device__ __forceinline__ bool cholN(const double *B, double alpha, double *Lf,
         for (int j = 0; j <= i; ++j) {
             double s = B[tri(i, j)] + (i == j ? alpha : 0.0);
 #pragma unroll
-            for (int k = 0; k < j; ++k) s -= Lf[tri(i, k)] * Lf[tri(j, k)];
+            for (int k = 0; k < j; ++k) s = fma(-Lf[tri(i, k)], Lf[tri(j, k)], s);
             if (i == j) {
                 if (!(s > 0.0)) { ok = false; s = 1.0; }
                 lmin2 = fmin(lmin2, s);
@@ -196,7 +200,7 @@ __device__ __forceinline__ void fwdN(const double *Lf, const double *inv, const 
     for (int i = 0; i < N; ++i) {
         double s = b[i];
 #pragma unroll
-        for (int k = 0; k < i; ++k) s -= Lf[tri(i, k)] * z[k];
+        for (int k = 0; k < i; ++k) s = fma(-Lf[tri(i, k)], z[k], s);
         z[i] = s * inv[i];
     }
 }
@@ -208,7 +212,7 @@ __device__ __forceinline__ void bwdN(const double *Lf, const double *inv, const 
     for (int i = N - 1; i >= 0; --i) {
         double s = z[i];
 #pragma unroll
-        for (int k = i + 1; k < N; ++k) s -= Lf[tri(k, i)] * p[k];
+        for (int k = i + 1; k < N; ++k) s = fma(-Lf[tri(k, i)], p[k], s);
         p[i] = s * inv[i];
     }
 }
@@ -540,7 +544,7 @@ __device__ __forceinline__ double eval_f(const R &T, const double *x, bool &fini
 #pragma clang fp contract(off)
             f = T.ld_w(l) * (M::value(x, e) - T.ld_y(l));
         }
-        if (!isfinite(f)) bad = 1.0; else acc += f * f;
+        if (!isfinite(f)) bad = 1.0; else acc = fma(f, f, acc);
     }
     double v[2] = {acc, bad};
     T.template block_sums<2>(v);
@@ -620,9 +624,9 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
         }
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            gacc[i] += Jr[i] * f0;
+            gacc[i] = fma(Jr[i], f0, gacc[i]);
 #pragma unroll
-            for (int j = 0; j <= i; ++j) Aacc[tri(i, j)] += Jr[i] * Jr[j];
+            for (int j = 0; j <= i; ++j) Aacc[tri(i, j)] = fma(Jr[i], Jr[j], Aacc[tri(i, j)]);
         }
     }
     // workgroup sums in the fixed order of block_sums (lanes by DPP butterfly, then waves 0..W-1): J^T J goes to the
@@ -714,7 +718,7 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
             {
                 double s = 0.0;
 #pragma unroll
-                for (int i = 0; i < N; ++i) { const double q = x[i] / sqrt(v[i]); s += q * q; }
+                for (int i = 0; i < N; ++i) { const double q = x[i] / sqrt(v[i]); s = fma(q, q, s); }
                 Delta = sqrt(s);
                 if (Delta == 0) Delta = 1.0;
             }

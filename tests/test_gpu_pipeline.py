@@ -123,3 +123,56 @@ def test_pipeline_with_orientation_trajectory(setup):
     assert np.array_equal(out1, out2, equal_nan=True)
     with pytest.raises(ValueError):
         DevicePipeline(st['ctx'], st['dev'], s['frames'], 32, s['R'], s['F'], s['dt'], q_orient=g['q32'][:5], **kw)
+
+
+def test_full_size_batch_search_equals_host_driven_search():
+    """BASELINE cfg3, one full batch (100 000 frames x 512 vectors, L = 2048): the one-launch model-order search inside
+    the pipeline against the host-driven search that calls the single-order solver order by order -- identical
+    selection and bit-identical parameters / chi^2 for every residue and every attempted order (1 513 fits, up to
+    286 evaluations each).  Also the size-independent properties of the result."""
+    import torch
+    from spinrelax_amd import synth
+    from spinrelax_amd import fitting_Ct_functions as fitCt
+    from spinrelax_amd.hip import Context
+    from spinrelax_amd.pipeline import DevicePipeline
+    s = synth.config_shapes(3)
+    V = 512
+    vecs_host = synth.synth_vectors_parallel(s['frames'], V, s['seed'])
+    ctx = Context(0)
+    dev = torch.device('cuda', 0)
+    vecs = torch.from_numpy(vecs_host).to(dev)
+    pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], q_rot=synth.Q_EXT, Diso=synth.DISO, aniso=synth.DANI,
+                          field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA, depth=1, stream=torch.cuda.Stream(device=dev))
+    out = pipe.step(vecs).copy()
+    sl = pipe.slots[0]
+    y, dy = sl.CtT.cpu().numpy(), sl.dCtT.cpu().numpy()
+    r = {k: v.copy() for k, v in sl.result.items()}
+    hist = sl.hist.cpu().numpy()
+    ctx.set_stream(0)
+    search = fitCt.OrderSearchBatch(pipe.t_host, y, pipe.listDoG, 0.5)
+    runner = fitCt.host_runner(pipe.t_host, y, dy, ctx=ctx)
+    while True:
+        req = search.request()
+        if req is None:
+            break
+        search.submit(*runner(req['nParams'], req['p0'], req['idx']))
+    assert np.array_equal(r['best'], search.best)
+    nfits = 0
+    for j, res in enumerate(search.per_order):
+        nP = res['nParams']
+        idx = np.flatnonzero(r['status'][j] != -100)
+        assert np.array_equal(idx, np.flatnonzero(~np.isnan(res['p0'][:, 0])))
+        assert np.array_equal(r['popt'][j][idx, :nP], res['popt'][idx])
+        assert np.array_equal(r['chisq'][j][idx], res['chiSq'][idx])
+        nfits += idx.size
+    assert nfits > 1000
+    # properties: C(t) starts near 1 and decays, every residue got a model, S2 + sum C <= 1 within bounds, histograms
+    # account for every frame, relaxation rates are positive and finite
+    assert np.all(y[:, 0] > 0.8) and np.all(y[:, 0] <= 1.0 + 1e-12) and np.all(y[:, -1] < y[:, 0])
+    assert np.all(r['best'] >= 0) and np.all(r['K'] >= 1)
+    assert np.all(r['S2'] >= 0) and np.all(r['S2'] <= 1) and np.all(r['C'] >= 0) and np.all(r['tau'] > 0)
+    for i in range(V):
+        assert np.all(np.diff(r['tau'][i, :r['K'][i]]) >= 0)
+    assert np.all(hist.sum(axis=1) == s['N'])
+    assert np.all(np.isfinite(out)) and np.all(out[0, :, 0, 0] > 0) and np.all(out[0, :, 1, 0] > out[0, :, 0, 0] * 0.5)
+    pipe.close()

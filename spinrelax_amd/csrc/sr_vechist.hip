@@ -24,6 +24,7 @@
 namespace {
 
 constexpr int kMaxEdges = 1024;
+constexpr int kInlineEdges = 128;      // 72 + 36 + 2 edges of the default histogram fit the kernel argument block
 
 struct VhArgs {
     const float *soa;
@@ -36,7 +37,8 @@ struct VhArgs {
     int nphi, ncos;
     int rotate;
     double qw, qx, qy, qz;
-    const double *edges; // device: nphi+1 then ncos+1
+    const double *edges; // device: nphi+1 then ncos+1; null = the edges travel in edges_inline (no upload per call)
+    double edges_inline[kInlineEdges];
     unsigned int *hist_u32;   // (nV, nphi*ncos)
     double *partials;         // (nV, nranges, 9)
 };
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void k_vechist(VhArgs a)
     const int rid = blockIdx.x;
     const int64_t v = blockIdx.y;
 
-    for (int i = tid; i < ne; i += 256) edges[i] = a.edges[i];
+    for (int i = tid; i < ne; i += 256) edges[i] = a.edges ? a.edges[i] : a.edges_inline[i];
     for (int i = tid; i < nbins; i += 256) h[i] = 0u;
     __syncthreads();
     const double *ephi = edges, *ecos = edges + a.nphi + 1;
@@ -297,13 +299,22 @@ int sr_rotate_hist_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t 
     }
     const int ne = nphi + 1 + ncos + 1;
     const size_t misc_bytes = (size_t)ne * sizeof(double);
-    double *edges_d = (double *)sr_workspace(ctx, SR_WS_IN3, misc_bytes);
+    double *edges_d = nullptr;
+    if (ne > kInlineEdges) {
+        edges_d = (double *)sr_workspace(ctx, SR_WS_IN3, misc_bytes);
+        if (!edges_d) return -5;
+    }
     unsigned int *h32 = (unsigned int *)sr_workspace(ctx, SR_WS_OUT2, (size_t)nV * nbins * sizeof(unsigned int));
     double *partials = (double *)sr_workspace(ctx, SR_WS_OUT3, (size_t)nV * a.nranges * 9 * sizeof(double));
-    if (!edges_d || !h32 || !partials) return -5;
-    SR_HIP(hipMemcpyAsync(edges_d, edges_phi_host, (size_t)(nphi + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    SR_HIP(hipMemcpyAsync(edges_d + nphi + 1, edges_cos_host, (size_t)(ncos + 1) * sizeof(double), hipMemcpyHostToDevice,
-                          ctx->stream));
+    if (!h32 || !partials) return -5;
+    if (edges_d) {
+        SR_HIP(hipMemcpyAsync(edges_d, edges_phi_host, (size_t)(nphi + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        SR_HIP(hipMemcpyAsync(edges_d + nphi + 1, edges_cos_host, (size_t)(ncos + 1) * sizeof(double), hipMemcpyHostToDevice,
+                              ctx->stream));
+    } else {
+        for (int i = 0; i <= nphi; ++i) a.edges_inline[i] = edges_phi_host[i];
+        for (int i = 0; i <= ncos; ++i) a.edges_inline[nphi + 1 + i] = edges_cos_host[i];
+    }
     SR_HIP(hipMemsetAsync(h32, 0, (size_t)nV * nbins * sizeof(unsigned int), ctx->stream));
     a.edges = edges_d; a.hist_u32 = h32; a.partials = partials;
     const size_t lds = (size_t)ne * sizeof(double) + 36 * sizeof(double) + (size_t)nbins * sizeof(unsigned int);

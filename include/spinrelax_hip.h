@@ -15,6 +15,12 @@
  *     entry points without "_dev" take HOST pointers, stage through the context's workspace and
  *     block until the result is in the caller's buffer;
  *   - one sr_ctx per GPU per thread; no internal locking; no callbacks or exceptions cross the ABI;
+ *   - the context owns growable work areas (raw C(t) sums, histogram counters, staging buffers).  They are
+ *     tied to no stream: sr_pack_soa*, sr_ct_palmer_f32_dev, sr_rotate_hist_f32_dev and every host-pointer entry
+ *     point must be issued on ONE stream at a time (sr_set_stream between them is fine once the previous work is
+ *     ordered before the next, e.g. same stream).  sr_expfit_order_search_f64_dev (with its `work` argument),
+ *     sr_expfit_lm_f64_dev (ditto), sr_jomega_relax_f64_dev and sr_transpose_f64_dev use caller memory only and
+ *     may run on several streams at once -- that is how spinrelax_amd/pipeline.py overlaps batches;
  *   - there is no CPU fallback: without a gfx950 device sr_create fails.
  */
 #ifndef SPINRELAX_HIP_H

@@ -7,9 +7,10 @@
 //   * one workgroup stages ONE (chunk r, vector v) time series of F frames into LDS as three float
 //     planes (x, y, z) -- 48 KB at F = 4096, so three workgroups share a CU's 160 KB;
 //   * the (j, lag) plane is cut into lag blocks of 128 lags; a wave owns a lag block, its 64 lanes
-//     are 4 j-strips x 16 lag-lanes, each lag-lane owns 8 consecutive lags.  Per step a lane loads
-//     8 a-values and 16 b-values per component with ds_read_b128 and issues 8x8x4 = 256 FMAs
-//     (3 for u(j).u(j+lag), 1 for the square-accumulate): 18 LDS b128 reads per 256 FMAs;
+//     are 4 j-strips x 16 lag-lanes, each lag-lane owns 8 consecutive lags.  Per step a lane needs
+//     8 a-values and a 16-frame b window per component and issues 8x8x4 = 256 FMAs (3 for u(j).u(j+lag), 1 for
+//     the square-accumulate).  Consecutive steps' b windows overlap by 8 frames: the window is kept as two
+//     8-frame halves that swap roles, so a step reads 6 + 6 = 12 ds_read_b128 (18 without the rotation);
 //   * LDS layout is "chunk-parity split, xyz-interleaved": 16-byte chunk c (4 frames of one component) lives
 //     in half (c & 1) at slot (c >> 1); a slot is 48 bytes = [x-chunk | y-chunk | z-chunk].  Lag-lanes whose
 //     windows start 8 floats (2 chunks) apart therefore read slots 48 bytes apart -- 3*l mod 16 is a
@@ -33,7 +34,7 @@ constexpr int kJT = 8;             // j values per lane step
 constexpr int kFlush = 8;          // lane steps between float32 -> float64 folds
 constexpr float kCenter = 8.0f;    // accumulators start at -kCenter so the <=16 terms (each in [0,1]) keep
                                    // the running float32 sum near zero: halves the accumulation rounding
-constexpr int kPad = 176;          // zero padding behind the series (max overshoot of a window: 167)
+constexpr int kPad = 192;          // zero padding behind the series (max overshoot of a window: 190)
 
 __host__ __device__ inline int64_t ct_Fp(int64_t F)
 {
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(W * 64, SR_CT_WAVES_EU) void k_ct_palmer(CtArgs a)
         if (k >= nb) continue;
         const int dw = k * kLagBlock;
         const int nj = F - dw;
-        const int S = (((nj + 3) >> 2) + 7) & ~7;          // strip length, multiple of 8
+        const int S = (((nj + 3) >> 2) + 15) & ~15;        // strip length, multiple of 16: an even number of steps
         const int iters = S >> 3;
         const float *pa0 = lds + ((g * S) >> 3) * 12;                              // even chunks of the a window
         const float *pa1 = pa0 + Hf;                                               // odd chunks
@@ -240,46 +241,62 @@ __global__ __launch_bounds__(W * 64, SR_CT_WAVES_EU) void k_ct_palmer(CtArgs a)
 #pragma unroll
         for (int d = 0; d < kLagsPerLane; ++d) acc64[d] = 0.0;
 
+        // The 16-frame b window of a step is [P | Q]: P = its first 8 frames, Q = the next 8.  The following step's
+        // window starts 8 frames later, i.e. with this step's Q -- so only ONE new half is read per step and the two
+        // halves swap roles (12 instead of 18 ds_read_b128 per 256 FMAs).
+        float Px[8], Py[8], Pz[8], Qx[8], Qy[8], Qz[8];
+#define SR_CT_LOAD_HALF(HX, HY, HZ, OFF)                                                         \
+        {                                                                                        \
+            const float4 t0 = *reinterpret_cast<const float4 *>(pb0 + (OFF));                   \
+            const float4 t1 = *reinterpret_cast<const float4 *>(pb0 + (OFF) + 4);               \
+            const float4 t2 = *reinterpret_cast<const float4 *>(pb0 + (OFF) + 8);               \
+            const float4 u0 = *reinterpret_cast<const float4 *>(pb1 + (OFF));                   \
+            const float4 u1 = *reinterpret_cast<const float4 *>(pb1 + (OFF) + 4);               \
+            const float4 u2 = *reinterpret_cast<const float4 *>(pb1 + (OFF) + 8);               \
+            HX[0] = t0.x; HX[1] = t0.y; HX[2] = t0.z; HX[3] = t0.w; HX[4] = u0.x; HX[5] = u0.y; HX[6] = u0.z; HX[7] = u0.w; \
+            HY[0] = t1.x; HY[1] = t1.y; HY[2] = t1.z; HY[3] = t1.w; HY[4] = u1.x; HY[5] = u1.y; HY[6] = u1.z; HY[7] = u1.w; \
+            HZ[0] = t2.x; HZ[1] = t2.y; HZ[2] = t2.z; HZ[3] = t2.w; HZ[4] = u2.x; HZ[5] = u2.y; HZ[6] = u2.z; HZ[7] = u2.w; \
+        }
+#define SR_CT_STEP(LX, LY, LZ, HX, HY, HZ)                                                       \
+        {                                                                                        \
+            float ax[kJT], ay[kJT], az[kJT], bx[16], by[16], bz[16];                             \
+            {                                                                                    \
+                const float4 tx = *reinterpret_cast<const float4 *>(pa0);                       \
+                const float4 ty = *reinterpret_cast<const float4 *>(pa0 + 4);                   \
+                const float4 tz = *reinterpret_cast<const float4 *>(pa0 + 8);                   \
+                const float4 ux = *reinterpret_cast<const float4 *>(pa1);                       \
+                const float4 uy = *reinterpret_cast<const float4 *>(pa1 + 4);                   \
+                const float4 uz = *reinterpret_cast<const float4 *>(pa1 + 8);                   \
+                ax[0] = tx.x; ax[1] = tx.y; ax[2] = tx.z; ax[3] = tx.w; ax[4] = ux.x; ax[5] = ux.y; ax[6] = ux.z; ax[7] = ux.w; \
+                ay[0] = ty.x; ay[1] = ty.y; ay[2] = ty.z; ay[3] = ty.w; ay[4] = uy.x; ay[5] = uy.y; ay[6] = uy.z; ay[7] = uy.w; \
+                az[0] = tz.x; az[1] = tz.y; az[2] = tz.z; az[3] = tz.w; az[4] = uz.x; az[5] = uz.y; az[6] = uz.z; az[7] = uz.w; \
+            }                                                                                    \
+            SR_CT_LOAD_HALF(HX, HY, HZ, 12)                                                      \
+            _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                      \
+                bx[t] = LX[t]; by[t] = LY[t]; bz[t] = LZ[t];                                     \
+                bx[8 + t] = HX[t]; by[8 + t] = HY[t]; bz[8 + t] = HZ[t];                         \
+            }                                                                                    \
+            _Pragma("unroll") for (int jj = 0; jj < kJT; ++jj) {                                 \
+                _Pragma("unroll") for (int d = 0; d < kLagsPerLane; ++d) {                       \
+                    float dot = ax[jj] * bx[jj + d];                                             \
+                    dot = fmaf(ay[jj], by[jj + d], dot);                                         \
+                    dot = fmaf(az[jj], bz[jj + d], dot);                                         \
+                    acc[d][jj & 3] = fmaf(dot, dot, acc[d][jj & 3]);                             \
+                }                                                                                \
+            }                                                                                    \
+            pa0 += 12; pa1 += 12; pb0 += 12; pb1 += 12;                                          \
+        }
+        SR_CT_LOAD_HALF(Px, Py, Pz, 0)
         for (int it0 = 0; it0 < iters; it0 += kFlush) {
             float acc[kLagsPerLane][4];
 #pragma unroll
             for (int d = 0; d < kLagsPerLane; ++d)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[d][q] = -kCenter;
-            const int n = min(kFlush, iters - it0);
-            for (int ii = 0; ii < n; ++ii) {
-                float ax[kJT], ay[kJT], az[kJT], bx[16], by[16], bz[16];
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const float *pa = hh ? pa1 : pa0;
-                    const float4 tx = *reinterpret_cast<const float4 *>(pa);
-                    const float4 ty = *reinterpret_cast<const float4 *>(pa + 4);
-                    const float4 tz = *reinterpret_cast<const float4 *>(pa + 8);
-                    ax[4 * hh] = tx.x; ax[4 * hh + 1] = tx.y; ax[4 * hh + 2] = tx.z; ax[4 * hh + 3] = tx.w;
-                    ay[4 * hh] = ty.x; ay[4 * hh + 1] = ty.y; ay[4 * hh + 2] = ty.z; ay[4 * hh + 3] = ty.w;
-                    az[4 * hh] = tz.x; az[4 * hh + 1] = tz.y; az[4 * hh + 2] = tz.z; az[4 * hh + 3] = tz.w;
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float *pb = ((c & 1) ? pb1 : pb0) + (c >> 1) * 12;
-                    const float4 tx = *reinterpret_cast<const float4 *>(pb);
-                    const float4 ty = *reinterpret_cast<const float4 *>(pb + 4);
-                    const float4 tz = *reinterpret_cast<const float4 *>(pb + 8);
-                    bx[4 * c] = tx.x; bx[4 * c + 1] = tx.y; bx[4 * c + 2] = tx.z; bx[4 * c + 3] = tx.w;
-                    by[4 * c] = ty.x; by[4 * c + 1] = ty.y; by[4 * c + 2] = ty.z; by[4 * c + 3] = ty.w;
-                    bz[4 * c] = tz.x; bz[4 * c + 1] = tz.y; bz[4 * c + 2] = tz.z; bz[4 * c + 3] = tz.w;
-                }
-#pragma unroll
-                for (int jj = 0; jj < kJT; ++jj) {
-#pragma unroll
-                    for (int d = 0; d < kLagsPerLane; ++d) {
-                        float dot = ax[jj] * bx[jj + d];
-                        dot = fmaf(ay[jj], by[jj + d], dot);
-                        dot = fmaf(az[jj], bz[jj + d], dot);
-                        acc[d][jj & 3] = fmaf(dot, dot, acc[d][jj & 3]);
-                    }
-                }
-                pa0 += 12; pa1 += 12; pb0 += 12; pb1 += 12;
+            const int n = min(kFlush, iters - it0);            // even
+            for (int ii = 0; ii < n; ii += 2) {
+                SR_CT_STEP(Px, Py, Pz, Qx, Qy, Qz)
+                SR_CT_STEP(Qx, Qy, Qz, Px, Py, Pz)
             }
 #pragma unroll
             for (int d = 0; d < kLagsPerLane; ++d) {
@@ -287,6 +304,8 @@ __global__ __launch_bounds__(W * 64, SR_CT_WAVES_EU) void k_ct_palmer(CtArgs a)
                 acc64[d] += (double)s + 4.0 * (double)kCenter;
             }
         }
+#undef SR_CT_STEP
+#undef SR_CT_LOAD_HALF
         // combine the 4 j strips: the lanes of strip 0 collect the partial sums of strips 1..3
         {
             const int s1 = strip_to_lane(1, l16), s2 = strip_to_lane(2, l16), s3 = strip_to_lane(3, l16);

@@ -198,6 +198,11 @@ def main():
             torch.cuda.synchronize()
 
         pipe.prime(vecs)                 # set-up (code objects, first touch of every in-flight slot), not a warm-up step
+        if world > 1:                    # set-up: communicator and gather buffers exist before anything is timed
+            for sl in pipe.slots:
+                gather_results(sl)
+            torch.cuda.synchronize()
+            dist.barrier()
         run_batches(args.warmup)
         events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
         torch.cuda.synchronize()

@@ -122,3 +122,80 @@ def test_multi_field_script(tmp_path):
     csa = np.loadtxt(out + '_CSA_opt.dat')
     np.testing.assert_allclose(csa[:, 1], g['fitted'], rtol=6e-6)             # %g keeps 6 significant digits
     assert len([f for f in os.listdir(str(tmp_path)) if f.startswith('mf_15N1H_') and f.endswith('.xvg')]) == 9
+
+
+def test_cfg5_scale_rscsa_recovers_planted_csa(tmp_path):
+    """BASELINE cfg5 scale (4 096 residues, 72 x 36 histogram each, 3 fields x R1/R2/NOE = 9
+    experiments): size-independent property -- experiments generated by the kernel itself at planted per-residue CSA
+    values are fitted back to those values by the rsCSA optimiser -- plus the wall time of the three stages."""
+    import time
+    from spinrelax_amd import general_scripts as gs
+    nrep = 128
+    base = fitCt.read_fittedCt_parameters(os.path.join(GOLD, 'cfg1_fittedCt.dat'))
+    names0 = base.get_names()
+    n0 = len(names0)
+    V = n0 * nrep
+    # 4 096 residue models: the 32 fitted models of cfg1, repeated with fresh residue numbers
+    src = open(os.path.join(GOLD, 'cfg1_fittedCt.dat')).read().split('# Residue: ')
+    head, blocks = src[0], src[1:]
+    assert len(blocks) == n0
+    fit_fn = str(tmp_path / 'cfg5_fittedCt.dat')
+    with open(fit_fn, 'w') as fp:
+        fp.write(head)
+        for r in range(nrep):
+            for b in blocks:
+                old = b.split('\n', 1)[0].strip()
+                fp.write('# Residue: %d\n%s' % (int(old) + 100 * r, b.split('\n', 1)[1]))
+    localCt = fitCt.read_fittedCt_parameters(fit_fn)
+    names = localCt.get_names()
+    assert len(names) == V
+    # histograms: the 32 cfg1 histograms, each repeated with multinomial resampling noise
+    h0 = np.load(os.path.join(GOLD, 'cfg1_vecHistogram.npz'), allow_pickle=True)
+    rng = np.random.default_rng(5)
+    data = np.concatenate([rng.poisson(h0['data'] + 0.01).astype(float) for _ in range(nrep)], axis=0)
+    npz_fn = str(tmp_path / 'cfg5_vecHistogram.npz')
+    gs.save_vecHistogram_npz(npz_fn, [int(x) for x in names], data, [h0['edges'][0], h0['edges'][1]])
+    grd = sd.globalRotationalDiffusion_Axisymmetric(D=[synth.DISO, synth.DANI])
+    grd.import_frame_vectors_npz(npz_fn)
+    planted = -170e-6 + 1e-6 * rng.uniform(-15, 15, V)
+    fields = (500.0, 600.133, 800.0)
+    kinds = ('R1', 'R2', 'NOE')
+
+    def make(files):
+        ex = sd.spinRelaxationExperiments(grd, localCt)
+        for f in files:
+            ex.add_experiment(f)
+        ex.set_global_zeta(synth.ZETA)
+        ex.map_experiment_peaknames_to_models()
+        return ex
+
+    # pass 1: placeholder experiment files to obtain the model values at the planted CSA
+    def write(vals, errs):
+        files = []
+        for k, (MHz, kind) in enumerate((f, kd) for f in fields for kd in kinds):
+            fn = str(tmp_path / ('e_%s_%d.dat' % (kind, round(MHz))))
+            with open(fn, 'w') as fp:
+                fp.write('# Type %s\n# NucleiA 15N\n# NucleiB 1H\n# Frequency %.3f\n' % (kind, MHz))
+                for i, nm in enumerate(names):
+                    fp.write('%s %.12g %.12g\n' % (nm, vals[k][i], errs[k][i]))
+            files.append(fn)
+        return files
+
+    ex = make(write(np.ones((9, V)), np.ones((9, V))))
+    ex.initialise_CSA_array(names, planted)
+    t0 = time.time()
+    ex.eval_all()
+    t_eval = time.time() - t0
+    truth = np.array([sp.values for sp in ex.spinrelax])
+    assert truth.shape == (9, V) and np.all(np.isfinite(truth))
+    ex = make(write(truth, np.abs(truth) * 0.02))
+    ex.parse_optimisation_params(['rsCSA'])
+    t0 = time.time()
+    chisq = ex.perform_optimisation(maxCycles=10, tol=1e-6)
+    t_opt = time.time() - t0
+    fitted = np.array(ex.get_first_csa())
+    print('cfg5 scale: %d residues x 9 experiments x 2592 bins: eval_all %.3f s, rsCSA optimisation %.2f s, chi^2 %.2e'
+          % (V, t_eval, t_opt, chisq))
+    np.testing.assert_allclose(fitted, planted, rtol=2e-5)
+    assert chisq < 1e-6
+    assert t_opt < 120

@@ -68,6 +68,7 @@ def parse():
     ap.add_argument('--fit-waves', type=int, default=0, help='wavefronts per residue in the model-order search (0 = library default)')
     ap.add_argument('--fit-lds', type=int, default=-1, help='1/0: keep residue data in LDS during the fits (-1 = library default)')
     ap.add_argument('--dev-skip-fits', action='store_true', help='DEVELOPMENT ONLY (invalid as a benchmark): leave the fits and the relaxation kernel out, to see the floor the C(t) side alone sets')
+    ap.add_argument('--hist-on-main', action='store_true', help='keep the histogram kernel in line with C(t) (only the pack runs beside it)')
     ap.add_argument('--depth', type=int, default=4, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
@@ -159,7 +160,7 @@ def main():
     pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], q_rot=q, Diso=synth.DISO, aniso=aniso,
                           field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA, depth=args.depth,
                           stream=torch.cuda.Stream(device=dev), reserve_cus=args.reserve_cus,
-                          fits_on_reserved_only=args.fits_on_reserved_only)
+                          fits_on_reserved_only=args.fits_on_reserved_only, hist_on_aux=not args.hist_on_main)
     stream = pipe.main
     if args.dev_skip_fits:
         pipe.stage_fit = lambda s=None: None
@@ -204,7 +205,7 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
         run_batches(args.warmup)
-        events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -242,7 +243,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ct_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    hist_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+    hist_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

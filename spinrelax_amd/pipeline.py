@@ -14,7 +14,9 @@ between; bench.py times it.  torch is used for device memory, streams and events
 goes through the C ABI.
 
 No host in the loop.  Between the vectors and the R1/R2/NOE table nothing returns to the host: a batch is
-seven kernel launches and one set of asynchronous copies into pinned memory.  (Until the model-order search moved
+nine kernel launches and one set of asynchronous copies into pinned memory, spread over three kinds of streams
+(main: C(t) and transposes; auxiliary: histogram of this batch and pack of the next one, beside C(t); one stream
+per batch in flight: fits, relaxation, copies).  (Until the model-order search moved
 onto the device the host drove it order by order -- five launches, ~30 small copies and ~3 ms of numpy per batch --
 and that latency chain, not the GPU, set the step time.)
 
@@ -74,6 +76,7 @@ class _Slot:
         self.h_ires = torch.empty((ni,), dtype=torch.int32).pin_memory()
         self.stream = stream
         self.front_done = None
+        self.hist_done = None
         self.done = None
         self.busy = False
         self.relax_out = None
@@ -94,7 +97,7 @@ class _Slot:
 class DevicePipeline:
     def __init__(self, ctx, device, frames, V, R, F, dt, q_rot=None, Diso=None, aniso=None, field_MHz=(600.133,),
                  zeta=0.890023, histBinX=72, listDoG=(2, 3, 5, 7, 9), csa=None, depth=1, stream=None, reserve_cus=0,
-                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None):
+                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None, hist_on_aux=True):
         self.ctx = ctx
         self.dev = device
         self.frames, self.V, self.R, self.F, self.dt = frames, V, R, F, dt
@@ -132,7 +135,14 @@ class DevicePipeline:
         for i in range(self.depth):
             st = self.main if self.depth == 1 else self._fit_stream(resv_words)
             self.slots.append(_Slot(device, V, self.L, R, self.nbins, len(self.listDoG), Pmax, E, st, need_fitwork))
+        # planes: two buffers and an auxiliary stream when batches overlap -- the pack of batch k+1 and the histogram of
+        # batch k (bandwidth / FP64 work) run beside the C(t) launch of batch k (FP32 issue bound) instead of in line with it
         self.soa = torch.empty((V, 3, self.Npad), device=device, dtype=torch.float32)
+        self.soa_bufs = [self.soa] + ([torch.empty_like(self.soa)] if self.depth > 1 else [])
+        self.aux = torch.cuda.Stream(device=device) if self.depth > 1 else None
+        self._packed_ev = [None, None]
+        self.hist_on_aux = hist_on_aux
+        self._ct_done_ev = [None, None]
         t = hostct.calculate_dt(dt, F * dt)
         self.t_host = np.ascontiguousarray(np.broadcast_to(t, (V, self.L)))
         self.t_dev = torch.from_numpy(self.t_host).to(device)
@@ -203,20 +213,23 @@ class DevicePipeline:
         self._owned_streams = []
 
     # ---- stages (each enqueues on the context's current stream) ----
-    def stage_pack(self, vecs):
+    def stage_pack(self, vecs, soa=None):
+        soa = self.soa if soa is None else soa
         if self.quat_dev is not None:
             self.ctx.pack_soa_rot_dev(vecs.data_ptr(), self.frames, vecs.shape[1], 0, self.V, self.quat_dev.data_ptr(),
-                                      self.soa.data_ptr(), self.Npad)
+                                      soa.data_ptr(), self.Npad)
         else:
-            self.ctx.pack_soa_dev(vecs.data_ptr(), self.frames, vecs.shape[1], 0, self.V, self.soa.data_ptr(), self.Npad)
+            self.ctx.pack_soa_dev(vecs.data_ptr(), self.frames, vecs.shape[1], 0, self.V, soa.data_ptr(), self.Npad)
 
-    def stage_ct(self, s=None):
+    def stage_ct(self, s=None, soa=None):
         s = s or self.slots[0]
-        self.ctx.ct_palmer_dev(self.soa.data_ptr(), self.Npad, self.R, self.F, self.V, s.Ct.data_ptr(), s.dCt.data_ptr())
+        soa = self.soa if soa is None else soa
+        self.ctx.ct_palmer_dev(soa.data_ptr(), self.Npad, self.R, self.F, self.V, s.Ct.data_ptr(), s.dCt.data_ptr())
 
-    def stage_hist(self, s=None):
+    def stage_hist(self, s=None, soa=None):
         s = s or self.slots[0]
-        self.ctx.rotate_hist_dev(self.soa.data_ptr(), self.Npad, self.N, self.V, self.q, self.edges[0], self.edges[1],
+        soa = self.soa if soa is None else soa
+        self.ctx.rotate_hist_dev(soa.data_ptr(), self.Npad, self.N, self.V, self.q, self.edges[0], self.edges[1],
                                  s.hist.data_ptr(), s.vecsum.data_ptr(), s.outer.data_ptr(), self.F)
 
     def stage_transpose(self, s=None):
@@ -256,30 +269,80 @@ class DevicePipeline:
 
     # ---- batch-level API ----
     def front(self, vecs, k, events=None, pack_next=None):
-        """Throughput half of batch k on the (CU-masked) main stream: pack, C(t), histogram, transposes.
-        pack_next: vectors of batch k+1, packed here already -- the planes buffer is free once the histogram has
-        read it, and the bandwidth-bound pack kernel would otherwise start together with the 512 fit workgroups
-        of batch k and crawl (1.9 ms instead of 0.4 ms in the kernel trace)."""
+        """Throughput half of batch k.  Serial form (depth 1): pack, C(t), histogram, transposes on the main stream.
+        Overlapped form: C(t) + transposes on the main stream; the histogram of batch k and the pack of batch k+1
+        (`pack_next`: its vectors) on the auxiliary stream, beside the C(t) launch, on alternating plane buffers.
+        events: [before C(t), after C(t), before histogram, after histogram] (the first two on the main stream)."""
         s = self.slots[k % self.depth]
+        if self.aux is None:
+            self.ctx.set_stream(self.main.cuda_stream)
+            with torch.cuda.stream(self.main):
+                self.stage_pack(vecs)
+                if events is not None:
+                    events[0].record(self.main)
+                self.stage_ct(s)
+                if events is not None:
+                    events[1].record(self.main)
+                    events[2].record(self.main)
+                self.stage_hist(s)
+                if events is not None:
+                    events[3].record(self.main)
+                self.stage_transpose(s)
+                s.front_done = torch.cuda.Event()
+                s.front_done.record(self.main)
+                s.hist_done = s.front_done
+            return s
+        b = k % 2
+        buf = self.soa_bufs[b]
+        if not self._packed:
+            # first batch of a run: nothing was packed ahead
+            self.ctx.set_stream(self.aux.cuda_stream)
+            with torch.cuda.stream(self.aux):
+                if self._ct_done_ev[b] is not None:
+                    self.aux.wait_event(self._ct_done_ev[b])
+                self.stage_pack(vecs, buf)
+                self._packed_ev[b] = torch.cuda.Event()
+                self._packed_ev[b].record(self.aux)
+        self._packed = False
         self.ctx.set_stream(self.main.cuda_stream)
         with torch.cuda.stream(self.main):
-            if not self._packed:
-                self.stage_pack(vecs)
-            self._packed = False
+            self.main.wait_event(self._packed_ev[b])
             if events is not None:
                 events[0].record(self.main)
-            self.stage_ct(s)
+            self.stage_ct(s, buf)
             if events is not None:
                 events[1].record(self.main)
-            self.stage_hist(s)
-            if events is not None:
-                events[2].record(self.main)
+            if not self.hist_on_aux:
+                if events is not None:
+                    events[2].record(self.main)
+                self.stage_hist(s, buf)
+                if events is not None:
+                    events[3].record(self.main)
+            self._ct_done_ev[b] = torch.cuda.Event()            # "the main stream is done with this plane buffer"
+            self._ct_done_ev[b].record(self.main)
             self.stage_transpose(s)
-            if pack_next is not None:
-                self.stage_pack(pack_next)
-                self._packed = True
             s.front_done = torch.cuda.Event()
             s.front_done.record(self.main)
+            s.hist_done = s.front_done
+        self.ctx.set_stream(self.aux.cuda_stream)
+        with torch.cuda.stream(self.aux):
+            if self.hist_on_aux:
+                if events is not None:
+                    events[2].record(self.aux)
+                self.stage_hist(s, buf)                 # ordered behind the pack of this buffer on the same stream
+                if events is not None:
+                    events[3].record(self.aux)
+                s.hist_done = torch.cuda.Event()
+                s.hist_done.record(self.aux)
+            if pack_next is not None:
+                nb = (k + 1) % 2
+                if self._ct_done_ev[nb] is not None:
+                    self.aux.wait_event(self._ct_done_ev[nb])       # C(t) of batch k-1 has read that buffer
+                self.stage_pack(pack_next, self.soa_bufs[nb])
+                self._packed_ev[nb] = torch.cuda.Event()
+                self._packed_ev[nb].record(self.aux)
+                self._packed = True
+        self.ctx.set_stream(self.main.cuda_stream)
         return s
 
     def back(self, k):
@@ -287,6 +350,7 @@ class DevicePipeline:
         s = self.slots[k % self.depth]
         if s.stream is not self.main:
             s.stream.wait_event(s.front_done)
+            s.stream.wait_event(s.hist_done)
         self.ctx.set_stream(s.stream.cuda_stream)
         with torch.cuda.stream(s.stream):
             self.stage_fit(s)

@@ -59,6 +59,8 @@ sr_ctx *sr_create(int device)
     ctx->stream = nullptr;
     ctx->fit_waves = 4;
     ctx->fit_lds = 1;
+    ctx->ct_fft = 0;
+    ctx->fft_table_ready = 0;
     if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) {
         sr_set_error("hipGetDeviceProperties failed");
         delete ctx;
@@ -96,6 +98,11 @@ int sr_set_option(sr_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "fit_waves")) {
         SR_REQUIRE(value == 1 || value == 2 || value == 4, -3, "sr_set_option: fit_waves must be 1, 2 or 4");
         ctx->fit_waves = value;
+        return 0;
+    }
+    if (!strcmp(name, "ct_fft")) {
+        SR_REQUIRE(value == 0 || value == 1, -3, "sr_set_option: ct_fft must be 0 or 1");
+        ctx->ct_fft = value;
         return 0;
     }
     if (!strcmp(name, "fit_lds")) {

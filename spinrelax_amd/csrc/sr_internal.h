@@ -7,7 +7,7 @@
 #include <cstring>
 #include "../../include/spinrelax_hip.h"
 
-#define SR_NSLOTS 13
+#define SR_NSLOTS 14
 
 struct sr_ctx {
     int device;
@@ -20,6 +20,8 @@ struct sr_ctx {
     // tuning (sr_set_option)
     int fit_waves;      // waves per residue in the model-order search: 1, 2 or 4
     int fit_lds;        // 1: stage t, y, 1/sigma of a residue in LDS when it fits; 0: read them from global memory
+    int ct_fft;         // 1: kernel 1 through the FFT formulation when the chunk length allows; 0: always the direct kernel
+    int fft_table_ready;
 };
 
 enum {
@@ -29,7 +31,8 @@ enum {
     SR_WS_OUT0, SR_WS_OUT1, SR_WS_OUT2, SR_WS_OUT3,
     SR_WS_IN0, SR_WS_IN1, SR_WS_IN2, SR_WS_IN3,
     SR_WS_MISC,
-    SR_WS_FIT           // residual work space of the fit kernel (when the caller passes none)
+    SR_WS_FIT,          // residual work space of the fit kernel (when the caller passes none)
+    SR_WS_FFT           // twiddle table of the FFT formulation of kernel 1
 };
 
 void sr_set_error(const char *fmt, ...);

@@ -69,6 +69,7 @@ def parse():
     ap.add_argument('--fit-lds', type=int, default=-1, help='1/0: keep residue data in LDS during the fits (-1 = library default)')
     ap.add_argument('--dev-skip-fits', action='store_true', help='DEVELOPMENT ONLY (invalid as a benchmark): leave the fits and the relaxation kernel out, to see the floor the C(t) side alone sets')
     ap.add_argument('--hist-on-main', action='store_true', help='keep the histogram kernel in line with C(t) (only the pack runs beside it)')
+    ap.add_argument('--ct-fft', type=int, default=-1, help='1/0: FFT formulation of the C(t) kernel (-1 = library default)')
     ap.add_argument('--depth', type=int, default=4, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
@@ -156,6 +157,8 @@ def main():
         ctx.set_option('fit_waves', args.fit_waves)
     if args.fit_lds >= 0:
         ctx.set_option('fit_lds', args.fit_lds)
+    if args.ct_fft >= 0:
+        ctx.set_option('ct_fft', args.ct_fft)
     triples = synth.exact_triples(s['R'], s['F'], V)
     pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], q_rot=q, Diso=synth.DISO, aniso=aniso,
                           field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA, depth=args.depth,

@@ -59,7 +59,7 @@ sr_ctx *sr_create(int device)
     ctx->stream = nullptr;
     ctx->fit_waves = 4;
     ctx->fit_lds = 1;
-    ctx->ct_fft = 0;
+    ctx->ct_fft = 1;
     ctx->fft_table_ready = 0;
     if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) {
         sr_set_error("hipGetDeviceProperties failed");

@@ -544,12 +544,31 @@ __global__ __launch_bounds__(256) void k_ct_fft(CtFftArgs a)
     // re-read from the planes for every pair (L2 hits) rather than kept in 96 registers across the transforms.
 #pragma unroll 1
     for (int pair = 0; pair < 3; ++pair) {
-        cplx sig[N1];
+        // the samples are re-read for every pair (L2 hits; keeping them in registers across the loop makes the
+        // compiler hoist all six products, 384 VGPRs).  All 3 N1 loads are issued before the first use -- with one
+        // wave per SIMD a load-use-load-use sequence pays the memory latency N1 times (1.5 ms of 3.6 ms).
+        asm volatile("" ::: "memory");
+        float xr[N1], yr[N1], zr[N1];
 #pragma unroll
         for (int n1 = 0; n1 < N1; ++n1) {
             const int n = tid + 256 * n1;
             const bool in = n < F;
-            const double x = in ? (double)px[n] : 0.0, y = in ? (double)py[n] : 0.0, z = in ? (double)pz[n] : 0.0;
+#if defined(SR_FFT_EXP) && SR_FFT_EXP == 1
+            xr[n1] = in ? 0.001f * (float)(n & 255) : 0.f; yr[n1] = in ? 0.5f : 0.f; zr[n1] = in ? 0.002f * (float)(pair + tid) : 0.f;
+#else
+            // unconditional loads from a clamped index + select: a conditional load becomes a branch, and a branch per
+            // sample serialises the memory latency (that alone was 1.5 ms of 3.6 ms)
+            const int nc = in ? n : 0;
+            const float xv = px[nc], yv = py[nc], zv = pz[nc];
+            xr[n1] = in ? xv : 0.f;
+            yr[n1] = in ? yv : 0.f;
+            zr[n1] = in ? zv : 0.f;
+#endif
+        }
+        cplx sig[N1];
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) {
+            const double x = (double)xr[n1], y = (double)yr[n1], z = (double)zr[n1];
             if (pair == 0) sig[n1] = {x * x, y * y};
             else if (pair == 1) sig[n1] = {z * z, x * y};
             else sig[n1] = {x * z, y * z};

@@ -517,7 +517,9 @@ __device__ __forceinline__ void fft_workgroup(cplx *v, cplx (*w)[8], cplx *lds, 
     __syncthreads();
 }
 
-template <int LOGN1>
+// HALF: the chunk fills at most the first half of the transform (F <= M/2, the F = 4096 / M = 8192 case): the upper
+// half of every thread's samples is known to be zero and is neither loaded nor multiplied
+template <int LOGN1, bool HALF>
 __global__ __launch_bounds__(256) void k_ct_fft(CtFftArgs a)
 {
     extern __shared__ __align__(16) unsigned char fft_smem[];
@@ -551,6 +553,10 @@ __global__ __launch_bounds__(256) void k_ct_fft(CtFftArgs a)
         float xr[N1], yr[N1], zr[N1];
 #pragma unroll
         for (int n1 = 0; n1 < N1; ++n1) {
+            if (HALF && n1 >= N1 / 2) {
+                xr[n1] = yr[n1] = zr[n1] = 0.f;
+                continue;
+            }
             const int n = tid + 256 * n1;
             const bool in = n < F;
 #if defined(SR_FFT_EXP) && SR_FFT_EXP == 1
@@ -621,16 +627,21 @@ __global__ __launch_bounds__(256) void k_ct_fft(CtFftArgs a)
     }
 }
 
-template <int LOGN1>
-int launch_ct_fft(sr_ctx *ctx, const CtFftArgs &a, int64_t series)
+template <int LOGN1, bool HALF>
+int launch_ct_fft_h(sr_ctx *ctx, const CtFftArgs &a, int64_t series)
 {
     const size_t lds = (size_t)fft_lds_slots(256 << LOGN1) * sizeof(cplx);
     if (lds > 64 * 1024)
-        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ct_fft<LOGN1>),
+        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ct_fft<LOGN1, HALF>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_ct_fft<LOGN1>), dim3((unsigned)series), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_ct_fft<LOGN1, HALF>), dim3((unsigned)series), dim3(256), lds, ctx->stream, a);
     SR_HIP(hipGetLastError());
     return 0;
+}
+template <int LOGN1>
+int launch_ct_fft(sr_ctx *ctx, const CtFftArgs &a, int64_t series)
+{
+    return a.F <= (128 << LOGN1) ? launch_ct_fft_h<LOGN1, true>(ctx, a, series) : launch_ct_fft_h<LOGN1, false>(ctx, a, series);
 }
 
 // mean / std over the R replicate chunks, calculate-Ct-from-traj.py:226-228

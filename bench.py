@@ -15,9 +15,11 @@ scaling on; weak scaling: every rank owns its own 512 vectors (rank r = vectors 
 of one synthetic trajectory).  `value` = exact triples of all ranks / wall time of a step.
 
 One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel (k_ct_palmer): 8 flop x exact triples per launch / mean launch time
+  roofline      dominant kernel (the C(t) kernel): 8 flop x exact triples per launch / mean launch time
                 (HIP events on the launch stream, inside the timed region) against the 157.3 TFLOP/s
                 FP32 vector peak (= the FP32 MFMA peak) of MI355X_MICROARCH.md; SURVEY.md section 8(d).
+                Since the kernel computes the same sums by FFT (k_ct_fft, 4 % of the direct flop, in float64)
+                `roofline.executed` gives the executed work against the FP64 vector peak as well.
   cpu_baseline  the reference's algorithm (per-lag float32 numpy einsum, calculate-Ct-from-traj.py:222-228,
                 restated in oracle/sr_oracle.py) timed on this host on a bounded sample (rank 0, N = 1).
 """
@@ -38,6 +40,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector = FP32 matrix peak
+PEAK_FP64_TFLOPS = 78.6           # MI355X_MICROARCH.md: FP64 vector
 PEAK_HBM_GBS = 8000.0
 
 
@@ -252,24 +255,42 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = triples * world / (elapsed / args.steps)
         achieved = 8.0 * triples / (ct_ms * 1e-3) / 1e12
-        traffic, traffic_src = measured_traffic('k_ct_palmer') if cfg == 3 and V == 512 else (None, None)
+        use_fft = (args.ct_fft != 0) and 1024 < s['F'] + s['L'] <= 8192
+        kname = 'k_ct_fft' if use_fft else 'k_ct_palmer'
+        traffic, traffic_src = measured_traffic(kname) if cfg == 3 and V == 512 else (None, None)
+        if use_fft:
+            M = 2048 if s['F'] + s['L'] <= 2048 else (4096 if s['F'] + s['L'] <= 4096 else 8192)
+            # executed float64 work of the FFT formulation: 4 complex M-point transforms (5 M log2 M flop each), the
+            # power spectra of 3 packed pairs (12 flop per frequency each) and the 6 products per frame
+            exec_flop = s['R'] * V * (4 * 5 * M * np.log2(M) + 3 * 12 * M + 6 * s['F'])
+            executed = {'formulation': 'Wiener-Khinchin: 6 float64 autocorrelations by FFT, whole %d-point transform resident in LDS' % M,
+                        'flop_per_launch': float(exec_flop), 'fraction_of_direct_flop': float(exec_flop / (8.0 * triples)),
+                        'achieved': float(exec_flop / (ct_ms * 1e-3) / 1e12), 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s (float64 vector)',
+                        'frac': float(exec_flop / (ct_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS),
+                        'note': 'latency-bound: one 4-wave workgroup per CU (151 KB LDS, 486 registers per lane)'}
+        else:
+            executed = {'formulation': 'direct shifted products, float32 FMA', 'flop_per_launch': 8.0 * triples, 'fraction_of_direct_flop': 1.0,
+                        'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s (float32 vector)', 'frac': achieved / PEAK_FP32_TFLOPS}
         best, _ = pipe.fit_best, None
         res = {
             'metric': 'frame-vector-lag triples/s, C(t) + fit + R1/R2/NOE pipeline',
             'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 dot products / f64 accumulation (C(t)); f64 (histogram, fit, J(w), R1/R2/NOE)',
+            'dtype': 'f64 (C(t) by FFT on f32 inputs; histogram, fit, J(w), R1/R2/NOE)' if use_fft else 'f32 dot products / f64 accumulation (C(t)); f64 (histogram, fit, J(w), R1/R2/NOE)',
             'data': 'synthetic',
             'config': {'workload': 'BASELINE cfg%d per GPU: %d frames x %d vectors, %d chunks x %d frames, %d lags, '
                                    '%s, fits 2/3/5/7/9 params, 1 field' % (cfg, s['frames'], V, s['R'], s['F'], s['L'],
                                                                            'axisymmetric D + q_ext + 72x36 histogram' if cfg == 3 else 'isotropic D'),
                        'vectors_per_gpu': V, 'exact_triples_per_gpu': triples, 'sharding': 'vectors (no data-path collective; all-gather of results)', 'batches_in_flight': pipe.depth, 'cus_reserved_for_fits': pipe.reserve_cus},
-            'roofline': {'bound': 'valu-fp32 (non-MFMA vector FMA; FP32 MFMA peak is the same 157.3)', 'kernel': 'k_ct_palmer',
+            'roofline': {'bound': 'valu-fp32 (non-MFMA vector FMA; FP32 MFMA peak is the same 157.3): ALGORITHMIC flop of the path, 8 per triple (SURVEY 8(d)), '
+                                  'over the measured duration of the kernel that computes C(t) -- see `executed` for what that kernel actually executes',
+                         'kernel': kname,
                          'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS,
                          'traffic': traffic, 'traffic_unit': 'bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)', 'traffic_source': traffic_src,
                          'algorithmic_bytes': 12 * s['N'] * V + 8 * s['R'] * s['L'] * V, 'kernel_ms': ct_ms, 'flop_per_triple': 8,
                          'streaming_equiv_GBps': 24.0 * triples / (ct_ms * 1e-3) / 1e9,
-                         'streaming_equiv_frac_of_hbm': 24.0 * triples / (ct_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                         'streaming_equiv_frac_of_hbm': 24.0 * triples / (ct_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                         'executed': executed},
             'stages_ms': {'ct_palmer': ct_ms, 'rotate_hist': hist_ms,
                           'rotate_hist_GBps': 12.0 * s['N'] * V / (hist_ms * 1e-3) / 1e9},
             'fit': {'residues': V, 'selected_orders': {str(pipe.listDoG[j]): int((best == j).sum()) for j in range(len(pipe.listDoG))},

@@ -112,6 +112,26 @@ def test_ct_ragged_and_edge_sizes(ctx, liboracle, F, R, V):
             assert dct_close(dCt, dCr, R, F)
 
 
+@pytest.mark.parametrize('F,R,V', [(683, 2, 3), (684, 2, 3), (1365, 3, 2), (1366, 2, 2), (2000, 2, 3), (2730, 2, 2), (2731, 2, 2),
+                                   (3000, 2, 2), (4096, 2, 3), (4097, 2, 2), (5000, 2, 2), (5461, 2, 1), (5462, 2, 1)])
+def test_ct_fft_formulation_all_transform_sizes(ctx, liboracle, F, R, V):
+    """The FFT formulation of kernel 1 (default for 1024 < F + L <= 8192) at every transform size and on both sides of
+    every switch: 2048 / 4096 / 8192 points, chunks that fill at most half of the transform (upper half skipped) and
+    chunks that do not, the last length that fits (5461) and the first that falls back to the direct kernel (5462).
+    Checked against the plain-C float64 oracle; the FFT path must be at float64 accuracy, far inside the 1e-6 bar."""
+    vecs = synth.synth_vectors(R * F + 5, V, seed=300 + F)
+    v4 = vecs[:R * F].reshape(R, F, V, 3)
+    Cr, dCr = c_oracle_ct(liboracle, v4)
+    Ct, dCt = ctx.ct_palmer(vecs, R, F)
+    assert Ct.shape == (F // 2, V)
+    uses_fft = 1024 < F + F // 2 <= 8192
+    assert relerr(Ct, Cr) < (1e-12 if uses_fft else RTOL)
+    assert np.max(np.abs(dCt - dCr)) <= (1e-12 if uses_fft else 1e-6) * max(1.0, np.max(np.abs(dCr)))
+    # same answer from the direct float64 mode
+    Ct1, dCt1 = ctx.ct_palmer(vecs, R, F, mode=1)
+    assert relerr(Ct, Ct1) < (1e-12 if uses_fft else RTOL)
+
+
 def test_ct_multi_file_chunk_starts(ctx, liboracle):
     """reformat_vecs_by_tau drops each file's tail separately (calculate-Ct-from-traj.py:259-272)."""
     from spinrelax_amd import ct as hostct
@@ -124,6 +144,16 @@ def test_ct_multi_file_chunk_starts(ctx, liboracle):
     Ct, dCt = ctx.ct_palmer(cat, R, F, chunk_start=starts)
     Cr, dCr = c_oracle_ct(liboracle, v4)
     assert relerr(Ct, Cr) < RTOL and dct_close(dCt, dCr, R, F)
+    # the same through the FFT formulation (chunk length 1200 -> 2048-point transforms)
+    a = synth.synth_vectors(3900, 3, seed=13)
+    b = synth.synth_vectors(2700, 3, seed=14)
+    F = 1200
+    v4 = o.reformat_vecs_by_tau([a, b], 1.0, float(F))
+    cat, starts, R = hostct.concat_with_chunk_starts([a, b], F)
+    assert R == v4.shape[0] == 5
+    Ct, dCt = ctx.ct_palmer(cat, R, F, chunk_start=starts)
+    Cr, dCr = c_oracle_ct(liboracle, v4)
+    assert relerr(Ct, Cr) < 1e-12 and np.max(np.abs(dCt - dCr)) < 1e-12
 
 
 def test_ct_size_independent_properties(ctx):

@@ -45,7 +45,8 @@ void         sr_destroy(sr_ctx *);
 int          sr_set_stream(sr_ctx *, void *hip_stream);   /* hipStream_t; NULL = default stream  */
 int          sr_sync(sr_ctx *);
 /* Tuning knobs: "fit_waves" = wavefronts per residue in the model-order search (1, 2 or 4; default 4: shortest
- * time per residue; 1: least resources per residue), "fit_lds" = 1/0 keep a residue's t, C(t), 1/sigma in LDS. */
+ * time per residue; 1: least resources per residue), "fit_lds" = 1/0 keep a residue's t, C(t), 1/sigma in LDS,
+ * "ct_fft" = 1/0 allow the FFT formulation of kernel 1 (default 1). */
 int          sr_set_option(sr_ctx *, const char *name, int value);
 /* Streams that partition the chip.  The fits of fitting_Ct_functions.py:278-345 are a latency chain of small
  * launches; queued behind a C(t) launch that fills every CU they starve (queue priority does not pre-empt
@@ -86,8 +87,13 @@ int sr_pack_soa_rot_f32_dev(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot
  *     p[r,v]      = (1/(F-delta)) * sum_j ( 1.5 (u[r,j,v].u[r,j+delta,v])^2 - 0.5 )
  *     Ct[d-1,v]   = mean_r p ;   dCt[d-1,v] = std_r(p, ddof=0) / (sqrt(R) - 1)
  * Ct, dCt are (L, nV) float64, row-major -- the reference's (nDeltas, nResidues).
- * mode 0: float32 dot products and short float32 partial sums folded into float64 (fast path);
- * mode 1: every product and sum in float64 (validation path, ~10x slower).
+ * mode 0 (production): the fastest formulation for the chunk length --
+ *           1024 < F + L <= 8192: the six autocorrelations of (x^2, y^2, z^2, xy, xz, yz) by float64 FFT
+ *           (Wiener-Khinchin, (u.u')^2 = sum_c w_c a_c a_c'), one workgroup per (chunk, vector) with the whole
+ *           2048/4096/8192-point transform in LDS; accurate to ~1e-15;  sr_set_option("ct_fft", 0) disables it;
+ *           otherwise: direct shifted products, float32 dot products and short float32 partial sums folded into
+ *           float64 (accurate to ~1e-8);
+ * mode 1: direct shifted products, every product and sum in float64 (validation path).
  * psum (optional, may be NULL): (nV, R, Lp) float64 raw sums  sum_j (u.u')^2, Lp = sr_ct_psum_stride(F). */
 int64_t sr_ct_psum_stride(int64_t F);
 int64_t sr_ct_max_frames_per_chunk(sr_ctx *);

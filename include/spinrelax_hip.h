@@ -97,6 +97,13 @@ int sr_pack_soa_rot_f32_dev(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot
  * psum (optional, may be NULL): (nV, R, Lp) float64 raw sums  sum_j (u.u')^2, Lp = sr_ct_psum_stride(F). */
 int64_t sr_ct_psum_stride(int64_t F);
 int64_t sr_ct_max_frames_per_chunk(sr_ctx *);
+/* the two halves of sr_ct_palmer_f32_dev as separate launches: raw sums per (vector, chunk, lag) into caller memory
+ * (psum: (nV, R, Lp) float64, required here), then mean / std over the chunks (calculate-Ct-from-traj.py:226-228).
+ * A pipeline with several batches in flight gives every batch its own psum; timing the first call alone gives the
+ * duration of the dominant kernel. */
+int sr_ct_palmer_sums_f32_dev(sr_ctx *, const float *soa, int64_t Npad, int64_t R, int64_t F, int64_t nV,
+                              const int64_t *chunk_start_host, int mode, double *psum);
+int sr_ct_finalize_f64_dev(sr_ctx *, const double *psum, int64_t R, int64_t F, int64_t nV, double *Ct, double *dCt);
 int sr_ct_palmer_f32_dev(sr_ctx *, const float *soa, int64_t Npad, int64_t R, int64_t F, int64_t nV,
                          const int64_t *chunk_start_host, int mode,
                          double *psum_ws, double *Ct, double *dCt);

@@ -757,36 +757,31 @@ int sr_pack_soa_rot_f32_dev(sr_ctx *ctx, const float *vecs, int64_t N, int64_t V
     return 0;
 }
 
-int sr_ct_palmer_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t R, int64_t F, int64_t nV,
-                         const int64_t *chunk_start_host, int mode, double *psum_ws, double *Ct, double *dCt)
+int sr_ct_palmer_sums_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t R, int64_t F, int64_t nV,
+                              const int64_t *chunk_start_host, int mode, double *psum)
 {
     SR_CHECK_CTX(ctx);
-    SR_REQUIRE(soa && Ct && dCt, -2, "sr_ct_palmer_f32_dev: null pointer");
-    SR_REQUIRE(R >= 1 && F >= 2 && nV >= 1, -3, "sr_ct_palmer_f32_dev: bad shape R=%lld F=%lld nV=%lld", (long long)R,
+    SR_REQUIRE(soa && psum, -2, "sr_ct_palmer_sums_f32_dev: null pointer");
+    SR_REQUIRE(R >= 1 && F >= 2 && nV >= 1, -3, "sr_ct_palmer_sums_f32_dev: bad shape R=%lld F=%lld nV=%lld", (long long)R,
                (long long)F, (long long)nV);
-    SR_REQUIRE(mode == 0 || mode == 1, -3, "sr_ct_palmer_f32_dev: mode must be 0 or 1");
+    SR_REQUIRE(mode == 0 || mode == 1, -3, "sr_ct_palmer_sums_f32_dev: mode must be 0 or 1");
     const int64_t Fp = ct_Fp(F);
     const size_t lds_bytes = (size_t)Fp * 3 * sizeof(float);
     SR_REQUIRE(lds_bytes <= sr_lds_limit(ctx), -4,
-               "sr_ct_palmer_f32_dev: F=%lld frames per chunk need %zu B of LDS (> %zu); max F is %lld",
+               "sr_ct_palmer_sums_f32_dev: F=%lld frames per chunk need %zu B of LDS (> %zu); max F is %lld",
                (long long)F, lds_bytes, sr_lds_limit(ctx),
                (long long)sr_ct_max_frames_per_chunk(ctx));
-    SR_REQUIRE(R * nV < (int64_t)1 << 30, -3, "sr_ct_palmer_f32_dev: too many series");
+    SR_REQUIRE(R * nV < (int64_t)1 << 30, -3, "sr_ct_palmer_sums_f32_dev: too many series");
     const int64_t L = F / 2;
     const int64_t Lp = sr_ct_psum_stride(F);
     if (chunk_start_host) {
         for (int64_t r = 0; r < R; ++r)
             SR_REQUIRE(chunk_start_host[r] >= 0 && chunk_start_host[r] + F <= Npad, -3,
-                       "sr_ct_palmer_f32_dev: chunk %lld start %lld out of range", (long long)r,
+                       "sr_ct_palmer_sums_f32_dev: chunk %lld start %lld out of range", (long long)r,
                        (long long)chunk_start_host[r]);
     } else {
-        SR_REQUIRE(R * F <= Npad, -3, "sr_ct_palmer_f32_dev: R*F=%lld exceeds Npad=%lld", (long long)(R * F),
+        SR_REQUIRE(R * F <= Npad, -3, "sr_ct_palmer_sums_f32_dev: R*F=%lld exceeds Npad=%lld", (long long)(R * F),
                    (long long)Npad);
-    }
-    double *psum = psum_ws;
-    if (!psum) {
-        psum = (double *)sr_workspace(ctx, SR_WS_PSUM, (size_t)(nV * R * Lp) * sizeof(double));
-        if (!psum) return -5;
     }
     int64_t *cs_dev = nullptr;
     if (chunk_start_host) {
@@ -826,12 +821,38 @@ int sr_ct_palmer_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t R,
         a.nslab = nb > 0 ? nb : 1;                   // one wave per workgroup, one lag block per wave
         rc = launch_ct<1>(ctx, a, series * a.nslab, lds_bytes);
     }
-    if (rc) return rc;
+    return rc;
+}
+
+int sr_ct_finalize_f64_dev(sr_ctx *ctx, const double *psum, int64_t R, int64_t F, int64_t nV, double *Ct, double *dCt)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(psum && Ct && dCt, -2, "sr_ct_finalize_f64_dev: null pointer");
+    SR_REQUIRE(R >= 1 && F >= 2 && nV >= 1, -3, "sr_ct_finalize_f64_dev: bad shape");
+    const int64_t L = F / 2;
+    const int64_t Lp = sr_ct_psum_stride(F);
     const int64_t tot = nV * L;
     hipLaunchKernelGGL(k_ct_finalize, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, psum, (int)R,
                        (int)F, (int)L, (int)Lp, nV, Ct, dCt);
     SR_HIP(hipGetLastError());
     return 0;
+}
+
+int sr_ct_palmer_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t R, int64_t F, int64_t nV,
+                         const int64_t *chunk_start_host, int mode, double *psum_ws, double *Ct, double *dCt)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(soa && Ct && dCt, -2, "sr_ct_palmer_f32_dev: null pointer");
+    SR_REQUIRE(R >= 1 && F >= 2 && nV >= 1, -3, "sr_ct_palmer_f32_dev: bad shape R=%lld F=%lld nV=%lld", (long long)R,
+               (long long)F, (long long)nV);
+    double *psum = psum_ws;
+    if (!psum) {
+        psum = (double *)sr_workspace(ctx, SR_WS_PSUM, (size_t)(nV * R * sr_ct_psum_stride(F)) * sizeof(double));
+        if (!psum) return -5;
+    }
+    int rc = sr_ct_palmer_sums_f32_dev(ctx, soa, Npad, R, F, nV, chunk_start_host, mode, psum);
+    if (rc) return rc;
+    return sr_ct_finalize_f64_dev(ctx, psum, R, F, nV, Ct, dCt);
 }
 
 int sr_ct_palmer_f32(sr_ctx *ctx, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV, int64_t R,

@@ -123,6 +123,14 @@ class Context:
         check(self.lib.sr_ct_palmer_f32_dev(self.h, soa_ptr, Npad, R, F, nV, _ptr(cs), int(mode), psum_ptr, Ct_ptr, dCt_ptr),
               'sr_ct_palmer_f32_dev')
 
+    def ct_sums_dev(self, soa_ptr, Npad, R, F, nV, psum_ptr, chunk_start=None, mode=0):
+        cs = None if chunk_start is None else np.ascontiguousarray(chunk_start, dtype=np.int64)
+        check(self.lib.sr_ct_palmer_sums_f32_dev(self.h, soa_ptr, Npad, R, F, nV, None if cs is None else _ptr(cs), mode, psum_ptr),
+              'sr_ct_palmer_sums_f32_dev')
+
+    def ct_finalize_dev(self, psum_ptr, R, F, nV, Ct_ptr, dCt_ptr):
+        check(self.lib.sr_ct_finalize_f64_dev(self.h, psum_ptr, R, F, nV, Ct_ptr, dCt_ptr), 'sr_ct_finalize_f64_dev')
+
     def psum_stride(self, F):
         return int(self.lib.sr_ct_psum_stride(F))
 

@@ -46,7 +46,7 @@ _STREAM_POOL = {}
 class _Slot:
     """Device buffers, pinned host mirrors and stream of one in-flight batch."""
 
-    def __init__(self, dev, V, L, R, nbins, nO, Pmax, E, stream, need_fitwork):
+    def __init__(self, dev, V, L, R, nbins, nO, Pmax, E, stream, need_fitwork, psum_len=0):
         f64 = dict(device=dev, dtype=torch.float64)
         i32 = dict(device=dev, dtype=torch.int32)
         Kmax = Pmax // 2
@@ -57,6 +57,7 @@ class _Slot:
         self.hist = torch.empty((V, nbins), **f64)
         self.vecsum = torch.empty((V, 3), **f64)
         self.outer = torch.empty((R, V, 6), **f64)
+        self.psum = torch.empty((psum_len,), **f64) if psum_len else None     # raw C(t) sums of this batch
         # every float64 / int32 result of the search in ONE buffer each, so that a batch needs two copies to the host
         self._dlayout = (('popt', (nO, V, Pmax)), ('dP', (nO, V, Pmax)), ('chisq', (nO, V)), ('S2', (V,)), ('chi', (V,)),
                          ('C', (V, Kmax)), ('tau', (V, Kmax)), ('relax', (E, V, 4, 2)))
@@ -134,7 +135,8 @@ class DevicePipeline:
         self.slots = []
         for i in range(self.depth):
             st = self.main if self.depth == 1 else self._fit_stream(resv_words)
-            self.slots.append(_Slot(device, V, self.L, R, self.nbins, len(self.listDoG), Pmax, E, st, need_fitwork))
+            self.slots.append(_Slot(device, V, self.L, R, self.nbins, len(self.listDoG), Pmax, E, st, need_fitwork,
+                                    psum_len=V * R * ctx.psum_stride(F)))
         # planes: two buffers and an auxiliary stream when batches overlap -- the pack of batch k+1 and the histogram of
         # batch k (bandwidth / FP64 work) run beside the C(t) launch of batch k (FP32 issue bound) instead of in line with it
         self.soa = torch.empty((V, 3, self.Npad), device=device, dtype=torch.float32)
@@ -221,10 +223,14 @@ class DevicePipeline:
         else:
             self.ctx.pack_soa_dev(vecs.data_ptr(), self.frames, vecs.shape[1], 0, self.V, soa.data_ptr(), self.Npad)
 
-    def stage_ct(self, s=None, soa=None):
+    def stage_ct(self, s=None, soa=None, mid_event=None):
+        """C(t): raw sums (the dominant kernel), then mean / std over the chunks.  mid_event is recorded between the two."""
         s = s or self.slots[0]
         soa = self.soa if soa is None else soa
-        self.ctx.ct_palmer_dev(soa.data_ptr(), self.Npad, self.R, self.F, self.V, s.Ct.data_ptr(), s.dCt.data_ptr())
+        self.ctx.ct_sums_dev(soa.data_ptr(), self.Npad, self.R, self.F, self.V, s.psum.data_ptr())
+        if mid_event is not None:
+            mid_event.record(torch.cuda.current_stream(self.dev))
+        self.ctx.ct_finalize_dev(s.psum.data_ptr(), self.R, self.F, self.V, s.Ct.data_ptr(), s.dCt.data_ptr())
 
     def stage_hist(self, s=None, soa=None):
         s = s or self.slots[0]
@@ -272,7 +278,8 @@ class DevicePipeline:
         """Throughput half of batch k.  Serial form (depth 1): pack, C(t), histogram, transposes on the main stream.
         Overlapped form: C(t) + transposes on the main stream; the histogram of batch k and the pack of batch k+1
         (`pack_next`: its vectors) on the auxiliary stream, beside the C(t) launch, on alternating plane buffers.
-        events: [before C(t), after C(t), before histogram, after histogram] (the first two on the main stream)."""
+        events: [before the C(t) kernel, after it (before its finalize), before histogram, after histogram]; the first
+        two on the main stream."""
         s = self.slots[k % self.depth]
         if self.aux is None:
             self.ctx.set_stream(self.main.cuda_stream)
@@ -280,9 +287,8 @@ class DevicePipeline:
                 self.stage_pack(vecs)
                 if events is not None:
                     events[0].record(self.main)
-                self.stage_ct(s)
+                self.stage_ct(s, mid_event=None if events is None else events[1])
                 if events is not None:
-                    events[1].record(self.main)
                     events[2].record(self.main)
                 self.stage_hist(s)
                 if events is not None:
@@ -309,9 +315,7 @@ class DevicePipeline:
             self.main.wait_event(self._packed_ev[b])
             if events is not None:
                 events[0].record(self.main)
-            self.stage_ct(s, buf)
-            if events is not None:
-                events[1].record(self.main)
+            self.stage_ct(s, buf, mid_event=None if events is None else events[1])
             if not self.hist_on_aux:
                 if events is not None:
                     events[2].record(self.main)

@@ -415,12 +415,65 @@ __host__ __device__ constexpr int bitrev(int p)
     for (int b = 0; b < LOGN; ++b) r |= ((p >> b) & 1) << (LOGN - 1 - b);
     return r;
 }
-// v[p] *= base^rev(p) for the bit-reversed output of fft_reg<LOGN>: base^k = A[k & 7] * B[k >> 3] with 8 + N/8 powers
-// held in registers (a full table of N powers would cost 4 N VGPRs next to the 4 N of the data)
-template <int LOGN>
+// d * exp(-2 pi i e / 24), e a compile-time constant
+template <int E>
+__device__ __forceinline__ cplx mul_w24(cplx d)
+{
+    if (E == 0) return d;
+    if (E == 6) return {d.im, -d.re};
+    if (E == 12) return {-d.re, -d.im};
+    constexpr double c[15] = {1.0, 0.9659258262890683, 0.8660254037844387, 0.7071067811865476, 0.5000000000000001,
+                              0.25881904510252074, 0.0, -0.25881904510252063, -0.4999999999999998, -0.7071067811865475,
+                              -0.8660254037844387, -0.9659258262890682, -1.0, -0.9659258262890683, -0.8660254037844388};
+    constexpr double s[15] = {0.0, 0.25881904510252074, 0.49999999999999994, 0.7071067811865475, 0.8660254037844386,
+                              0.9659258262890683, 1.0, 0.9659258262890683, 0.8660254037844387, 0.7071067811865476,
+                              0.49999999999999994, 0.258819045102521, 0.0, -0.2588190451025208, -0.4999999999999997};
+    return {fma(d.re, c[E], d.im * s[E]), fma(d.im, c[E], -(d.re * s[E]))};
+}
+
+// First stage of the four-step transform: N1 samples per thread -> N1 frequencies k1, in place; v[p] holds X[k1(p)].
+template <int N1>
+struct Stage1 {
+    static constexpr int LOG = N1 == 8 ? 3 : (N1 == 16 ? 4 : 5);
+    __host__ __device__ static constexpr int k1(int p) { return bitrev<LOG>(p); }
+    __device__ static __forceinline__ void run(cplx *v) { fft_reg<LOG>(v); }
+};
+// 24 = 3 x 8 (transform length 6144 = F + L for the F = 4096 chunks: a quarter less work than 8192): n1 = 8 a + b,
+// k1 = ka + 3 kb; 3-point transforms over a, twiddle w_24^(b ka), 8-point transforms over b
+template <int B>
+__device__ __forceinline__ void dft3_col(cplx *v, cplx (*y)[8])
+{
+    constexpr double h = 0.8660254037844386;            // sqrt(3)/2
+    const cplx x0 = v[B], x1 = v[8 + B], x2 = v[16 + B];
+    const cplx t = {x1.re + x2.re, x1.im + x2.im}, d = {x1.re - x2.re, x1.im - x2.im};
+    const cplx m = {fma(-0.5, t.re, x0.re), fma(-0.5, t.im, x0.im)};
+    const cplx r = {h * d.im, -h * d.re};                // -i sqrt(3)/2 (x1 - x2)
+    y[0][B] = {x0.re + t.re, x0.im + t.im};
+    y[1][B] = mul_w24<B>(cplx{m.re + r.re, m.im + r.im});
+    y[2][B] = mul_w24<2 * B>(cplx{m.re - r.re, m.im - r.im});
+    if constexpr (B + 1 < 8) dft3_col<B + 1>(v, y);
+}
+template <>
+struct Stage1<24> {
+    __host__ __device__ static constexpr int k1(int p) { return (p >> 3) + 3 * bitrev<3>(p & 7); }
+    __device__ static __forceinline__ void run(cplx *v)
+    {
+        cplx y[3][8];
+        dft3_col<0>(v, y);
+#pragma unroll
+        for (int ka = 0; ka < 3; ++ka) {
+            fft_reg<3>(y[ka]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[8 * ka + q] = y[ka][q];
+        }
+    }
+};
+
+// v[p] *= base^k(p), k(p) < N: base^k = A[k & 7] * B[k >> 3] with 8 + N/8 powers held in registers (a full table of N
+// powers would cost 4 N VGPRs next to the 4 N of the data)
+template <int N, class KOF>
 __device__ __forceinline__ void apply_twiddles(cplx *v, cplx base)
 {
-    constexpr int N = 1 << LOGN;
     constexpr int NA = N < 8 ? N : 8, NB = N / 8 > 0 ? N / 8 : 1;
     cplx A[NA], B[NB];
     A[0] = {1.0, 0.0};
@@ -434,9 +487,7 @@ __device__ __forceinline__ void apply_twiddles(cplx *v, cplx base)
     }
 #pragma unroll
     for (int p = 0; p < N; ++p) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int k = bitrev<LOGN>(p);
+        const int k = KOF::k1(p);
         if (k == 0) continue;
         const cplx t = (k >> 3) == 0 ? A[k & 7] : ((k & 7) == 0 ? B[k >> 3] : cmul(A[k & 7], B[k >> 3]));
         v[p] = cmul(v[p], t);
@@ -448,12 +499,14 @@ __device__ __forceinline__ void apply_twiddles(cplx *v, cplx base)
 __host__ __device__ constexpr int fft_pad(int a) { return a + (a >> 3) + 8 * (a >> 8); }
 __host__ __device__ constexpr int fft_lds_slots(int M) { return M + (M >> 3) + 8 * (M >> 8); }
 
-__global__ void k_fft_init_table(double *tab)       // tab[2t], tab[2t+1] = cos, -sin of 2 pi t / 8192, t < 1024
+// tab[2t], tab[2t+1] = cos, -sin of 2 pi t / 8192 for t < 1024, followed by the same for 2 pi t / 6144, t < 256
+__global__ void k_fft_init_table(double *tab)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 1024) {
+    if (t < 1280) {
         double sn, cs;
-        sincospi((double)t / 4096.0, &sn, &cs);
+        if (t < 1024) sincospi((double)t / 4096.0, &sn, &cs);
+        else sincospi((double)(t - 1024) / 3072.0, &sn, &cs);
         tab[2 * t] = cs;
         tab[2 * t + 1] = -sn;
     }
@@ -463,26 +516,26 @@ struct CtFftArgs {
     const float *soa;
     int64_t Npad;
     const int64_t *chunk_start;   // device, may be null
-    const double *tab;            // w_8192^t, t < 1024
+    const double *tab;            // w_8192^t, t < 1024, then w_6144^t, t < 256
     double *psum;                 // (nV, R, Lp)
     int R, F, L, Lp;
 };
 
 // one full transform of the thread's N1 samples v[] (natural order, sample n = tid + 256 n1) -> the thread's
 // G = N1/8 groups of 8 spectrum values w[j][p] = X[g + 32 N1 rev3(p)], g = tid + 256 j.  Ends with a barrier.
-template <int LOGN1>
+template <int N1>
 __device__ __forceinline__ void fft_workgroup(cplx *v, cplx (*w)[8], cplx *lds, const double *__restrict__ tab, int tid)
 {
-    constexpr int N1 = 1 << LOGN1;
     constexpr int G = N1 / 8;
-    constexpr int TS = 8192 / (N1 * 256);          // table stride of w_M
+    constexpr bool kPow2 = (N1 & (N1 - 1)) == 0;
     // step 1: N1-point transforms over n1, twiddle w_M^(n2 k1), to LDS as element k1*256 + n2
-    fft_reg<LOGN1>(v);
-    apply_twiddles<LOGN1>(v, cplx{tab[2 * (TS * tid)], tab[2 * (TS * tid) + 1]});
+    Stage1<N1>::run(v);
     {
+        const int ti = kPow2 ? (8192 / (N1 * 256)) * tid : 1024 + tid;      // w_M^tid
+        apply_twiddles<N1, Stage1<N1>>(v, cplx{tab[2 * ti], tab[2 * ti + 1]});
         cplx *b = lds + tid + (tid >> 3);
 #pragma unroll
-        for (int p = 0; p < N1; ++p) b[fft_pad(bitrev<LOGN1>(p) * 256)] = v[p];
+        for (int p = 0; p < N1; ++p) b[fft_pad(Stage1<N1>::k1(p) * 256)] = v[p];
     }
     __syncthreads();
     // step 2: thread (k1, lo), active while k1 < N1: 32-point transforms over h (n2 = lo + 8 h), twiddle w_256^(lo k2a)
@@ -494,14 +547,24 @@ __device__ __forceinline__ void fft_workgroup(cplx *v, cplx (*w)[8], cplx *lds, 
 #pragma unroll
         for (int h = 0; h < 32; ++h) u[h] = b[9 * h];
         fft_reg<5>(u);
-        apply_twiddles<5>(u, cplx{tab[2 * (32 * lo)], tab[2 * (32 * lo) + 1]});
+        apply_twiddles<32, Stage1<32>>(u, cplx{tab[2 * (32 * lo)], tab[2 * (32 * lo) + 1]});
     }
     __syncthreads();
     if (act) {
         // element (k1 + N1 k2a)*8 + lo
-        cplx *b = lds + 9 * k1 + lo;
+        if constexpr (kPow2) {
+            cplx *b = lds + 9 * k1 + lo;
 #pragma unroll
-        for (int p = 0; p < 32; ++p) b[fft_pad(8 * N1 * bitrev<5>(p))] = u[p];
+            for (int p = 0; p < 32; ++p) b[fft_pad(8 * N1 * bitrev<5>(p))] = u[p];
+        } else {
+            // 8 N1 is not a power of two: the per-thread and the constant part of the slot can carry into each other
+            const int t = 8 * k1 + lo;
+#pragma unroll
+            for (int p = 0; p < 32; ++p) {
+                const int c = 8 * N1 * bitrev<5>(p);
+                lds[t + c + ((t + c) >> 3) + 8 * ((t + c) >> 8)] = u[p];
+            }
+        }
     }
     __syncthreads();
     // step 3: thread q, groups g = q + 256 j: 8-point transforms over lo
@@ -517,16 +580,16 @@ __device__ __forceinline__ void fft_workgroup(cplx *v, cplx (*w)[8], cplx *lds, 
     __syncthreads();
 }
 
-// HALF: the chunk fills at most the first half of the transform (F <= M/2, the F = 4096 / M = 8192 case): the upper
-// half of every thread's samples is known to be zero and is neither loaded nor multiplied
-template <int LOGN1, bool HALF>
+// HALF: the chunk fills at most 256 NZ samples (NZ = N1/2, or 16 of 24: the F = 4096 case): the thread's samples
+// beyond NZ are known to be zero and are not loaded
+template <int N1, bool HALF>
 __global__ __launch_bounds__(256) void k_ct_fft(CtFftArgs a)
 {
     extern __shared__ __align__(16) unsigned char fft_smem[];
     cplx *lds = reinterpret_cast<cplx *>(fft_smem);
-    constexpr int N1 = 1 << LOGN1;
     constexpr int M = N1 * 256;
     constexpr int G = N1 / 8;
+    constexpr int NZ = HALF ? (N1 == 24 ? 16 : N1 / 2) : N1;
     const int tid = threadIdx.x;
     const int v = blockIdx.x / a.R, r = blockIdx.x - v * a.R;
     const int F = a.F;
@@ -553,7 +616,7 @@ __global__ __launch_bounds__(256) void k_ct_fft(CtFftArgs a)
         float xr[N1], yr[N1], zr[N1];
 #pragma unroll
         for (int n1 = 0; n1 < N1; ++n1) {
-            if (HALF && n1 >= N1 / 2) {
+            if (n1 >= NZ) {
                 xr[n1] = yr[n1] = zr[n1] = 0.f;
                 continue;
             }
@@ -580,7 +643,7 @@ __global__ __launch_bounds__(256) void k_ct_fft(CtFftArgs a)
             else sig[n1] = {x * z, y * z};
         }
         cplx w[G][8];
-        fft_workgroup<LOGN1>(sig, w, lds, a.tab, tid);
+        fft_workgroup<N1>(sig, w, lds, a.tab, tid);
         // spectrum to LDS in frequency order, then every thread reads the mirror frequency of its own ones
 #pragma unroll
         for (int j = 0; j < G; ++j)
@@ -593,7 +656,8 @@ __global__ __launch_bounds__(256) void k_ct_fft(CtFftArgs a)
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int k = tid + 256 * j + 32 * N1 * bitrev<3>(p);
-                const cplx zm = lds[fft_pad((M - k) & (M - 1))];
+                const int km = k == 0 ? 0 : M - k;
+                const cplx zm = lds[km + (km >> 3) + 8 * (km >> 8)];
                 const cplx zk = w[j][p];
                 // P = (Z(k) + conj Z(M-k)) / 2, Q = (Z(k) - conj Z(M-k)) / (2i)
                 const double sr = zk.re + zm.re, si = zk.im - zm.im;
@@ -614,7 +678,7 @@ __global__ __launch_bounds__(256) void k_ct_fft(CtFftArgs a)
         for (int n1 = 0; n1 < N1; ++n1) sig[n1] = fb[fft_pad(256 * n1)];
         __syncthreads();
         cplx w[G][8];
-        fft_workgroup<LOGN1>(sig, w, lds, a.tab, tid);
+        fft_workgroup<N1>(sig, w, lds, a.tab, tid);
         double *out = a.psum + ((int64_t)v * a.R + r) * a.Lp;
         const double inv = 1.0 / (double)M;
 #pragma unroll
@@ -627,21 +691,22 @@ __global__ __launch_bounds__(256) void k_ct_fft(CtFftArgs a)
     }
 }
 
-template <int LOGN1, bool HALF>
+template <int N1, bool HALF>
 int launch_ct_fft_h(sr_ctx *ctx, const CtFftArgs &a, int64_t series)
 {
-    const size_t lds = (size_t)fft_lds_slots(256 << LOGN1) * sizeof(cplx);
+    const size_t lds = (size_t)fft_lds_slots(256 * N1) * sizeof(cplx);
     if (lds > 64 * 1024)
-        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ct_fft<LOGN1, HALF>),
+        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ct_fft<N1, HALF>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_ct_fft<LOGN1, HALF>), dim3((unsigned)series), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_ct_fft<N1, HALF>), dim3((unsigned)series), dim3(256), lds, ctx->stream, a);
     SR_HIP(hipGetLastError());
     return 0;
 }
-template <int LOGN1>
+template <int N1>
 int launch_ct_fft(sr_ctx *ctx, const CtFftArgs &a, int64_t series)
 {
-    return a.F <= (128 << LOGN1) ? launch_ct_fft_h<LOGN1, true>(ctx, a, series) : launch_ct_fft_h<LOGN1, false>(ctx, a, series);
+    constexpr int NZ = N1 == 24 ? 16 : N1 / 2;
+    return a.F <= 256 * NZ ? launch_ct_fft_h<N1, true>(ctx, a, series) : launch_ct_fft_h<N1, false>(ctx, a, series);
 }
 
 // mean / std over the R replicate chunks, calculate-Ct-from-traj.py:226-228
@@ -798,10 +863,10 @@ int sr_ct_palmer_sums_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64
     // FFT formulation: chunk + lags must fit a 2048 / 4096 / 8192-point transform (shorter chunks are cheap anyway)
     const int64_t need = F + L;
     if (mode == 0 && ctx->ct_fft && need > 1024 && need <= 8192) {
-        double *tab = (double *)sr_workspace(ctx, SR_WS_FFT, 2048 * sizeof(double));
+        double *tab = (double *)sr_workspace(ctx, SR_WS_FFT, 2560 * sizeof(double));
         if (!tab) return -5;
         if (!ctx->fft_table_ready) {
-            hipLaunchKernelGGL(k_fft_init_table, dim3(4), dim3(256), 0, ctx->stream, tab);
+            hipLaunchKernelGGL(k_fft_init_table, dim3(5), dim3(256), 0, ctx->stream, tab);
             SR_HIP(hipGetLastError());
             SR_HIP(hipStreamSynchronize(ctx->stream));      // once per context: later launches may come on other streams
             ctx->fft_table_ready = 1;
@@ -809,8 +874,9 @@ int sr_ct_palmer_sums_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64
         CtFftArgs fa;
         fa.soa = soa; fa.Npad = Npad; fa.chunk_start = cs_dev; fa.tab = tab; fa.psum = psum;
         fa.R = (int)R; fa.F = (int)F; fa.L = (int)L; fa.Lp = (int)Lp;
-        rc = need <= 2048 ? launch_ct_fft<3>(ctx, fa, series) : need <= 4096 ? launch_ct_fft<4>(ctx, fa, series)
-                                                                            : launch_ct_fft<5>(ctx, fa, series);
+        rc = need <= 2048 ? launch_ct_fft<8>(ctx, fa, series)
+             : need <= 4096 ? launch_ct_fft<16>(ctx, fa, series)
+             : need <= 6144 ? launch_ct_fft<24>(ctx, fa, series) : launch_ct_fft<32>(ctx, fa, series);
     } else if (mode == 1) {
         a.nslab = 1;
         rc = launch_ct<4>(ctx, a, series, lds_bytes);

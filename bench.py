@@ -259,7 +259,8 @@ def main():
         kname = 'k_ct_fft' if use_fft else 'k_ct_palmer'
         traffic, traffic_src = measured_traffic(kname) if cfg == 3 and V == 512 else (None, None)
         if use_fft:
-            M = 2048 if s['F'] + s['L'] <= 2048 else (4096 if s['F'] + s['L'] <= 4096 else 8192)
+            need = s['F'] + s['L']
+            M = 2048 if need <= 2048 else (4096 if need <= 4096 else (6144 if need <= 6144 else 8192))
             # executed float64 work of the FFT formulation: 4 complex M-point transforms (5 M log2 M flop each), the
             # power spectra of 3 packed pairs (12 flop per frequency each) and the 6 products per frame
             exec_flop = s['R'] * V * (4 * 5 * M * np.log2(M) + 3 * 12 * M + 6 * s['F'])
@@ -267,7 +268,7 @@ def main():
                         'flop_per_launch': float(exec_flop), 'fraction_of_direct_flop': float(exec_flop / (8.0 * triples)),
                         'achieved': float(exec_flop / (ct_ms * 1e-3) / 1e12), 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s (float64 vector)',
                         'frac': float(exec_flop / (ct_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS),
-                        'note': 'latency-bound: one 4-wave workgroup per CU (151 KB LDS, 486 registers per lane)'}
+                        'note': 'latency-bound: one 4-wave workgroup per CU (114-152 KB LDS, ~450 registers per lane)'}
         else:
             executed = {'formulation': 'direct shifted products, float32 FMA', 'flop_per_launch': 8.0 * triples, 'fraction_of_direct_flop': 1.0,
                         'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s (float32 vector)', 'frac': achieved / PEAK_FP32_TFLOPS}

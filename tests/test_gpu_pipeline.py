@@ -176,3 +176,25 @@ def test_full_size_batch_search_equals_host_driven_search():
     assert np.all(hist.sum(axis=1) == s['N'])
     assert np.all(np.isfinite(out)) and np.all(out[0, :, 0, 0] > 0) and np.all(out[0, :, 1, 0] > out[0, :, 0, 0] * 0.5)
     pipe.close()
+
+
+def test_bench_two_ranks_on_one_device(tmp_path):
+    """The N > 1 path of bench.py (per-rank vector shards, result all-gathers on their own stream, max-over-ranks
+    timing) rehearsed with two ranks sharing this GPU over gloo -- RCCL needs one GPU per rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES='6')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29577', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--vectors', '64',
+           '--backend', 'gloo', '--all-ranks-on-device0', '--no-cpu-baseline']
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1                                   # rank 0 alone reports
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['steps'] == 4
+    assert j['config']['vectors_per_gpu'] == 64 and j['value'] > 0
+    assert j['fit']['residues'] == 64 and j['fit']['unfitted'] == 0

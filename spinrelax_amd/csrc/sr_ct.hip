@@ -3,7 +3,12 @@
 //
 // Reference semantics: calculate_Ct_Palmer, calculate-Ct-from-traj.py:200-238 (see include/spinrelax_hip.h).
 //
-// Kernel 1 design (DESIGN.md section "C(t) kernel"):
+// Kernel 1 exists in two formulations that produce the same raw sums S[lag] = sum_j (u(j).u(j+lag))^2 per chunk:
+//   k_ct_fft     float64 Wiener-Khinchin (six autocorrelations by FFT, the whole transform in LDS): production path for
+//                1024 < F + L <= 8192, ~4 % of the direct flop count, accurate to 1e-15 (see further down);
+//   k_ct_palmer  direct shifted products in float32 (or float64 in validation mode): every other chunk length.
+//
+// Direct kernel design:
 //   * one workgroup stages ONE (chunk r, vector v) time series of F frames into LDS as three float
 //     planes (x, y, z) -- 48 KB at F = 4096, so three workgroups share a CU's 160 KB;
 //   * the (j, lag) plane is cut into lag blocks of 128 lags; a wave owns a lag block, its 64 lanes

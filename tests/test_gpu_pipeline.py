@@ -198,3 +198,36 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['steps'] == 4
     assert j['config']['vectors_per_gpu'] == 64 and j['value'] > 0
     assert j['fit']['residues'] == 64 and j['fit']['unfitted'] == 0
+
+
+def test_bench_json_contract():
+    """bench.py prints ONE JSON line with the agreed keys, the roofline object of the dominant kernel (measured live with
+    events on its stream) and the CPU baseline timed beside it (a 1-vector sample here to keep the test short)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '6', '--warmup', '1', '--cpu-sample-vectors', '1'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in j, k
+    assert j['n_gpus'] == 1 and j['steps'] == 6 and j['warmup'] == 1 and j['higher_is_better'] is True
+    assert j['unit'] == 'triples/s' and j['data'] == 'synthetic' and j['vs_baseline'] is None and 'workload' in j['config']
+    assert abs(j['value'] - j['config']['exact_triples_per_gpu'] / (j['ms_per_step'] * 1e-3)) <= 1e-6 * j['value']
+    r = j['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernel_ms', 'executed'):
+        assert k in r, k
+    assert r['kernel'] == 'k_ct_fft' and 0 < r['kernel_ms'] < j['ms_per_step'] * 1.05
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert 0 < r['executed']['frac'] < 1 and r['executed']['fraction_of_direct_flop'] < 0.1
+    c = j['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0
+    assert j['fit']['unfitted'] == 0

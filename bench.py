@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 # multiplexes streams onto 4 queues by default and streams that share a queue serialise (spinrelax_amd/pipeline.py).
 # Not more than needed: two processes with 16 queues each on ONE GPU oversubscribe the hardware queues and the
 # scheduler's time-slicing makes a step 20x slower (seen in the 2-rank rehearsal on one device).
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '10')
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector = FP32 matrix peak
 PEAK_FP64_TFLOPS = 78.6           # MI355X_MICROARCH.md: FP64 vector
@@ -66,14 +66,14 @@ def parse():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', type=str, default='cfg3', choices=['cfg2', 'cfg3'])
     ap.add_argument('--vectors', type=int, default=None, help='vectors per GPU (default: the config value)')
-    ap.add_argument('--reserve-cus', type=int, default=0, help='CUs kept free of the C(t)/histogram kernels for the latency-bound fit kernels (CU-masked stream; 0 = no partition)')
-    ap.add_argument('--fits-on-reserved-only', action='store_true', help='confine the fit kernels to the reserved CUs')
+    ap.add_argument('--reserve-cus', type=int, default=128, help='CUs kept free of the C(t)/histogram kernels for the latency-bound fit kernels (CU-masked stream; 0 = no partition)')
+    ap.add_argument('--fits-on-reserved-only', type=int, default=1, help='1/0: confine the fit kernels to the reserved CUs (strict partition)')
     ap.add_argument('--fit-waves', type=int, default=0, help='wavefronts per residue in the model-order search (0 = library default)')
     ap.add_argument('--fit-lds', type=int, default=-1, help='1/0: keep residue data in LDS during the fits (-1 = library default)')
     ap.add_argument('--dev-skip-fits', action='store_true', help='DEVELOPMENT ONLY (invalid as a benchmark): leave the fits and the relaxation kernel out, to see the floor the C(t) side alone sets')
     ap.add_argument('--hist-on-main', action='store_true', help='keep the histogram kernel in line with C(t) (only the pack runs beside it)')
     ap.add_argument('--ct-fft', type=int, default=-1, help='1/0: FFT formulation of the C(t) kernel (-1 = library default)')
-    ap.add_argument('--depth', type=int, default=4, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
+    ap.add_argument('--depth', type=int, default=6, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
     ap.add_argument('--all-ranks-on-device0', action='store_true', help='rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)')
@@ -166,7 +166,7 @@ def main():
     pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], q_rot=q, Diso=synth.DISO, aniso=aniso,
                           field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA, depth=args.depth,
                           stream=torch.cuda.Stream(device=dev), reserve_cus=args.reserve_cus,
-                          fits_on_reserved_only=args.fits_on_reserved_only, hist_on_aux=not args.hist_on_main)
+                          fits_on_reserved_only=bool(args.fits_on_reserved_only), hist_on_aux=not args.hist_on_main)
     stream = pipe.main
     if args.dev_skip_fits:
         pipe.stage_fit = lambda s=None: None

@@ -189,7 +189,7 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     env = dict(os.environ, GPU_MAX_HW_QUEUES='6')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29577', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--vectors', '64',
-           '--backend', 'gloo', '--all-ranks-on-device0', '--no-cpu-baseline']
+           '--backend', 'gloo', '--all-ranks-on-device0', '--no-cpu-baseline', '--depth', '3', '--reserve-cus', '0']
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]

@@ -305,6 +305,11 @@ def main():
         else:
             res['cpu_baseline'] = None
         print(json.dumps(res))
+    # deterministic teardown while the HIP runtime is alive: streams, pinned mirrors and the context's work areas go
+    # here, not in __del__ / static destructors at interpreter exit
+    pipe.close()
+    del vecs
+    ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -35,7 +35,7 @@ extern "C" {
 
 typedef struct sr_ctx sr_ctx;
 
-#define SR_ABI_VERSION 1
+#define SR_ABI_VERSION 2
 
 /* ---- context, memory, timing ------------------------------------------------------------- */
 int          sr_abi_version(void);
@@ -61,6 +61,15 @@ int          sr_free(sr_ctx *, void *dev_ptr);
 int          sr_memcpy_h2d(sr_ctx *, void *dev_dst, const void *host_src, size_t bytes);
 int          sr_memcpy_d2h(sr_ctx *, void *host_dst, const void *dev_src, size_t bytes);
 int          sr_memset(sr_ctx *, void *dev_dst, int value, size_t bytes);
+/* Asynchronous copies on the context's stream (no synchronisation; the host buffer should be pinned: sr_host_alloc) and
+ * page-locked host memory owned by the library.  A pipeline that keeps several batches in flight returns each batch's
+ * results with these, on that batch's own stream -- no other runtime keeps per-stream state about the copies, so the
+ * streams can be destroyed deterministically (sr_stream_destroy) when the pipeline closes. */
+int          sr_memcpy_d2h_async(sr_ctx *, void *host_dst, const void *dev_src, size_t bytes);
+int          sr_memcpy_h2d_async(sr_ctx *, void *dev_dst, const void *host_src, size_t bytes);
+void        *sr_host_alloc(sr_ctx *, size_t bytes);              /* hipHostMalloc; NULL on failure */
+int          sr_host_free(sr_ctx *, void *host_ptr);
+int          sr_device_sync(sr_ctx *);                           /* every stream of the context's device */
 /* HIP events on the context's stream (the stream the kernels are launched on). */
 int          sr_timer_start(sr_ctx *);
 int          sr_timer_stop_ms(sr_ctx *, float *elapsed_ms);     /* synchronises on the stop event */

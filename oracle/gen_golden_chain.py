@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""
+gen_golden_chain.py -- END-TO-END fixtures: what the reference CHAIN produces from a synthetic trajectory,
+
+    vectors -> calculate_Ct_Palmer (calculate-Ct-from-traj.py:200-238)
+            -> rotate_vector_simd + Lambert histogram (:541-630)
+            -> optimised_curve_fitting per residue (calculate-fitted-Ct.py:161-178, fitting_Ct_functions.py:278-345)
+            -> _fittedCt.dat -> read_fittedCt_parameters -> zeta scaling (calculate-relaxations-from-Ct.py:692-750)
+            -> J(omega), R1 / R2 / NOE / rho with the histogram as weights (:125-191)
+
+run with the REAL reference imported from /root/reference (oracle/ref_loader.py), for
+  * cfg1 (32 residues), cfg2 (first 16 residues), cfg3s (8 residues) -- the same inputs as the per-stage fixtures;
+  * cfg4s: 8 vectors out of shard r = 3 (vectors 768..1023) of the 2 048-vector cfg4 trajectory.
+
+Two variants of the chain are stored per case:
+  mem   float64 C(t) handed to the fit IN MEMORY (what a device-resident pipeline can reproduce);
+  txt   float64 C(t) written with the reference's own writer and read back (general_scripts.py:275-290 prints 8
+        significant digits), the fit parameters then written / read through _fittedCt.dat (%g, 6 digits) -- what
+        run-all.bash's file chain does.
+The R1/R2/NOE/rho tables are float64 (the reference functions evaluated without the final float32 cast of
+_obtain_R1R2NOErho's datablock); the float32 datablock is stored next to them.
+
+Run in the build container only:   make -C oracle ref && python oracle/gen_golden_chain.py
+Fixtures are data; no reference source text is stored.  TEST INFRASTRUCTURE ONLY.
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import gen_golden as gg                              # noqa: E402  (loads the reference; its main() is not run)
+from spinrelax_amd import synth                     # noqa: E402
+
+ref = gg.ref
+GOLD = gg.GOLD
+CFG4_SHARD = 3
+CFG4_LOCAL = (0, 1, 37, 100, 128, 201, 254, 255)      # shard-local indices of the 8 golden vectors
+
+
+def ref_table_f64(S2_list, C_list, tau_list, hist, edges, names, MHz, zeta, Diso, Dani):
+    """R1/R2/NOE/rho x (mean, sigma) float64 (4, n, 2) symmetric-top with histogram weights, isotropic (4, n), and the
+    float32 datablocks _obtain_R1R2NOErho returns.  S2/C/tau: the fitted (unscaled) parameters per residue."""
+    n = len(S2_list)
+    S2s = [zeta * s for s in S2_list]                                         # calculate-relaxations-from-Ct.py:747-750
+    Cs = [zeta * np.asarray(c, dtype=float) for c in C_list]
+    taus = [np.asarray(t, dtype=float) for t in tau_list]
+    with tempfile.TemporaryDirectory() as td:
+        npz_fn = os.path.join(td, 'h_vecHistogram.npz')
+        np.savez_compressed(npz_fn, names=names, dataType='LambertCylindrical', bHistogram=True,
+                            edges=np.array(edges, dtype=object), axisLabels=['phi', 'cos(theta)'], data=hist)
+        resIDs, vecXH, weights = gg.quiet(ref.calcRelax.read_vector_distribution_from_file, npz_fn)
+    B0 = 2.0 * np.pi * (MHz * 1e6) / 267.513e6
+    RObj = ref.sd.relaxationModel('NH', B0)
+    RObj.set_time_unit('ps')
+    csa = np.repeat(RObj.gX.csa, n)
+    RObj.set_rotdif_model('rigid_sphere_D', Diso)
+    iso32 = gg.quiet(ref.calcRelax._obtain_R1R2NOErho, RObj, n, S2s, Cs, taus, None, weights=None, CSAvaluesArray=csa)
+    iso64 = np.zeros((4, n))
+    for i in range(n):
+        J = ref.sd.J_combine_isotropic_exp_decayN(RObj.omega, 1.0 / (6.0 * Diso), S2s[i], Cs[i], taus[i])
+        R1, R2, NOE = RObj.get_relax_from_J(J, CSAvalue=csa[i])
+        iso64[:, i] = [R1, R2, NOE, RObj.get_rho_from_J(J)]
+    Dperp = 3. * Diso / (2 + Dani)
+    Dpar = Dani * Dperp
+    RObj.set_rotdif_model('rigid_symmtop_D', Dpar, Dperp)
+    sym32 = gg.quiet(ref.calcRelax._obtain_R1R2NOErho, RObj, n, S2s, Cs, taus, vecXH, weights=weights, CSAvaluesArray=csa)
+    sym64 = np.zeros((4, n, 2))
+    for i in range(n):
+        Jm = ref.sd.J_combine_symmtop_exp_decayN(RObj.omega, vecXH[i], Dpar, Dperp, S2s[i], Cs[i], taus[i])
+        r1, r2, noe = RObj.get_relax_from_J_simd(Jm, CSAvalue=csa[i])
+        rho = RObj.get_rho_from_J_simd(Jm)
+        for k, a in enumerate((r1, r2, noe, rho)):
+            sym64[k, i] = ref.gm.weighted_average_stdev(a, weights[i])
+    return dict(iso64=iso64, sym64=sym64, iso32=iso32, sym32=sym32)
+
+
+def fit_in_memory(names, t, Ct, dCt, listDoG=(2, 3, 5, 7, 9)):
+    """optimised_curve_fitting per residue on in-memory float64 arrays (calculate-fitted-Ct.py:161-178)."""
+    n = len(names)
+    tl = [np.asarray(t, dtype=float) for _ in range(n)]
+    yl = [np.ascontiguousarray(Ct[:, i]) for i in range(n)]
+    dyl = [np.ascontiguousarray(dCt[:, i]) for i in range(n)]
+    ac, res = gg.ref_fit_all(names, tl, yl, dyl, listDoG)
+    return ac, res
+
+
+def params_of(ac):
+    S2, C, tau, _ = ac.get_params_as_list()
+    return list(S2), [np.array(c) for c in C], [np.array(x) for x in tau]
+
+
+def pack(prefix, res, S2, C, tau, tab):
+    n = len(S2)
+    K = np.array([len(c) for c in C])
+    Cp = np.zeros((n, 4))
+    Tp = np.ones((n, 4))
+    for i in range(n):
+        Cp[i, :K[i]] = C[i]
+        Tp[i, :K[i]] = tau[i]
+    out = {prefix + 'sel_nParams': res['sel_nParams'], prefix + 'sel_chi': res['sel_chi'], prefix + 'S2': np.array(S2),
+           prefix + 'C': Cp, prefix + 'tau': Tp, prefix + 'K': K, prefix + 'trial_chi': res['trial_chi'],
+           prefix + 'trial_quality': res['trial_quality']}
+    for k, v in tab.items():
+        out[prefix + k] = v
+    return out
+
+
+def gen_chain(tag, vecs, s, names, q=synth.Q_EXT, MHz=synth.FIELD_MHZ, extra=None):
+    """vecs: (frames, n, 3) float32, the golden vectors only."""
+    n = vecs.shape[1]
+    v4 = gg.quiet(ref.calcCt.reformat_vecs_by_tau, [vecs], s['dt'], s['tau_memory'])
+    t = ref.calcCt.calculate_dt(s['dt'], s['tau_memory'])
+    Ct, dCt = gg.quiet(ref.calcCt.calculate_Ct_Palmer, v4.astype(np.float64))
+    v3, rot, avg, hist, edges, S2blk, S2n = gg.ref_vec_stage(s, v4, q)
+    out = dict(input_sha=gg.sha(vecs), names=np.array(names), t=t, Ct64=Ct, dCt64=dCt, hist=hist.astype(np.uint32),
+               avgvec=avg, S2_tau=S2blk, q=np.array(q), MHz=MHz, zeta=synth.ZETA, Diso=synth.DISO, Dani=synth.DANI)
+    if extra:
+        out.update(extra)
+    # --- variant "mem": float64 arrays straight into the fit, parameters straight into the relaxation functions
+    ac, res = fit_in_memory(names, t, Ct, dCt)
+    S2, C, tau = params_of(ac)
+    tab = ref_table_f64(S2, C, tau, hist, edges, names, MHz, synth.ZETA, synth.DISO, synth.DANI)
+    out.update(pack('mem_', res, S2, C, tau, tab))
+    # --- variant "txt": through the reference's own text files
+    with tempfile.TemporaryDirectory() as td:
+        fn = os.path.join(td, 'x_Ctint.dat')
+        ref.gs.print_sxylist(fn, names, t, np.stack((Ct.T, dCt.T), axis=-1))
+        legs, tl, yl, dyl = ref.gs.load_sxydylist(fn, 'legend')
+        legs = [int(x) for x in legs]
+        ac2, res2 = gg.ref_fit_all(legs, tl, yl, dyl)
+        fit_fn = os.path.join(td, 'x_fittedCt.dat')
+        ac2.export(fileName=fit_fn, style='xmgrace')
+        back = ref.fitCt.read_fittedCt_parameters(fit_fn)
+        S2b, Cb, taub = params_of(back)
+    tab2 = ref_table_f64(S2b, Cb, taub, hist, edges, names, MHz, synth.ZETA, synth.DISO, synth.DANI)
+    out.update(pack('txt_', res2, S2b, Cb, taub, tab2))
+    gg.save('%s_chain.npz' % tag, **out)
+    return out
+
+
+def main():
+    man_fn = os.path.join(GOLD, 'MANIFEST.json')
+    with open(man_fn) as fp:
+        manifest = json.load(fp)
+    gg.manifest.clear()
+    # cfg1: 32 residues
+    s1 = synth.config_shapes(1)
+    gen_chain('cfg1', synth.synth_config(1), s1, list(range(2, 2 + s1['V'])))
+    # cfg2: first 16 residues
+    s2 = synth.config_shapes(2)
+    gen_chain('cfg2', synth.synth_config(2, nvec=16), s2, list(range(2, 18)))
+    # cfg3 slice: 8 residues
+    s3 = synth.config_shapes(3)
+    gen_chain('cfg3s', synth.synth_config(3, nvec=8), s3, list(range(2, 10)))
+    # cfg4: 8 vectors of shard 3 (256 vectors per GPU, 8 GPUs)
+    s4 = synth.config_shapes(4)
+    per = s4['V'] // 8
+    v0 = CFG4_SHARD * per
+    cols = [v0 + i for i in CFG4_LOCAL]
+    vecs = np.concatenate([synth.synth_vectors(s4['frames'], 1, s4['seed'], v0=c) for c in cols], axis=1)
+    gen_chain('cfg4s', vecs, s4, [c + 2 for c in cols], extra=dict(shard=CFG4_SHARD, shard_v0=v0, shard_nV=per,
+                                                                   local_index=np.array(CFG4_LOCAL), Vtot=s4['V']))
+    manifest.update(gg.manifest)
+    with open(man_fn, 'w') as fp:
+        json.dump(manifest, fp, indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main()

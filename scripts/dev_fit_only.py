@@ -40,7 +40,7 @@ def main():
         pipe.stage_relax(sl)
         pipe.stage_download(sl)
         torch.cuda.synchronize()
-        r = sl.host_views()
+        r = sl.host_results()
         tried = r['status'] != -100
         print('nfev per order', [int(r['nfev'][j][tried[j]].sum()) for j in range(5)], 'max', [int(r['nfev'][j].max()) for j in range(5)])
 

@@ -33,6 +33,11 @@ SIGNATURES = {
     'sr_memcpy_h2d': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     'sr_memcpy_d2h': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     'sr_memset': (c_int, [c_void_p, c_void_p, c_int, c_size_t]),
+    'sr_memcpy_d2h_async': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'sr_memcpy_h2d_async': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'sr_host_alloc': (c_void_p, [c_void_p, c_size_t]),
+    'sr_host_free': (c_int, [c_void_p, c_void_p]),
+    'sr_device_sync': (c_int, [c_void_p]),
     'sr_timer_start': (c_int, [c_void_p]),
     'sr_timer_stop_ms': (c_int, [c_void_p, POINTER(c_float)]),
     'sr_pack_soa_f32_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64]),
@@ -78,6 +83,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2
 LIB_PATH = os.environ.get('SPINRELAX_HIP_LIB', LIB_PATH)      # alternative build of the same ABI
 
 
@@ -128,8 +134,8 @@ def load():
             raise SpinRelaxHipError('%s does not export %s (stale build?)' % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
-    if lib.sr_abi_version() != 1:
-        raise SpinRelaxHipError('ABI version mismatch: library %d, binding 1' % lib.sr_abi_version())
+    if lib.sr_abi_version() != ABI_VERSION:
+        raise SpinRelaxHipError('ABI version mismatch: library %d, binding %d' % (lib.sr_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -18,8 +18,10 @@ void *sr_workspace(sr_ctx *ctx, int slot, size_t bytes)
     if (bytes == 0) bytes = 16;
     if (ctx->slot_bytes[slot] >= bytes) return ctx->slot[slot];
     if (ctx->slot[slot]) {
-        // make sure nothing enqueued on the stream still uses the old buffer
-        (void)hipStreamSynchronize(ctx->stream);
+        // One context is driven from several streams (spinrelax_amd/pipeline.py: main, auxiliary, one per batch in
+        // flight), so work that still reads the old buffer may sit on ANY of them: wait for the whole device, not for
+        // the stream that happens to be current.  Growth is rare (sizes repeat from batch to batch).
+        (void)hipDeviceSynchronize();
         (void)hipFree(ctx->slot[slot]);
         ctx->slot[slot] = nullptr;
         ctx->slot_bytes[slot] = 0;
@@ -83,7 +85,7 @@ void sr_destroy(sr_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();      // the work areas may be in use on any stream the caller has driven the context from
     for (int i = 0; i < SR_NSLOTS; ++i)
         if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
     (void)hipEventDestroy(ctx->ev0);
@@ -197,6 +199,46 @@ int sr_memcpy_d2h(sr_ctx *ctx, void *dst, const void *src, size_t bytes)
     SR_CHECK_CTX(ctx);
     SR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sr_memcpy_d2h_async(sr_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(dst && src, -2, "sr_memcpy_d2h_async: null pointer");
+    SR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+int sr_memcpy_h2d_async(sr_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(dst && src, -2, "sr_memcpy_h2d_async: null pointer");
+    SR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+void *sr_host_alloc(sr_ctx *ctx, size_t bytes)
+{
+    if (!ctx) { sr_set_error("null sr_ctx"); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { sr_set_error("hipSetDevice failed"); return nullptr; }
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) { sr_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+
+int sr_host_free(sr_ctx *ctx, void *p)
+{
+    SR_CHECK_CTX(ctx);
+    if (p) SR_HIP(hipHostFree(p));
+    return 0;
+}
+
+int sr_device_sync(sr_ctx *ctx)
+{
+    SR_CHECK_CTX(ctx);
+    SR_HIP(hipDeviceSynchronize());
     return 0;
 }
 

@@ -753,12 +753,8 @@ __global__ __launch_bounds__(256) void k_transpose_f64(const double *__restrict_
 template <int W>
 int launch_ct(sr_ctx *ctx, const CtArgs &a, int64_t nblocks, size_t lds_bytes)
 {
-    static size_t configured = 0;
-    if (lds_bytes > configured) {
-        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ct_palmer<W>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        configured = lds_bytes;
-    }
+    if (int rc = sr_grant_lds(ctx, W == 1 ? SR_K_CT1 : SR_K_CT4, reinterpret_cast<const void *>(&k_ct_palmer<W>), lds_bytes))
+        return rc;
     hipLaunchKernelGGL(k_ct_palmer<W>, dim3((unsigned)nblocks), dim3(W * 64), lds_bytes, ctx->stream, a);
     SR_HIP(hipGetLastError());
     return 0;

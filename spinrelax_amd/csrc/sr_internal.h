@@ -22,7 +22,12 @@ struct sr_ctx {
     int fit_lds;        // 1: stage t, y, 1/sigma of a residue in LDS when it fits; 0: read them from global memory
     int ct_fft;         // 1: kernel 1 through the FFT formulation when the chunk length allows; 0: always the direct kernel
     int fft_table_ready;
+    // largest dynamic-LDS size already granted per kernel family (hipFuncSetAttribute is a per-DEVICE setting and a
+    // context is bound to one device, so the cache lives here and not in a process-wide static)
+    size_t lds_granted[8];
 };
+
+enum { SR_K_CT1 = 0, SR_K_CT4, SR_K_VECHIST, SR_K_DQ, SR_K_MISC };
 
 enum {
     SR_WS_VECS = 0,     // staged host vectors (frame-major)
@@ -63,6 +68,19 @@ static inline size_t sr_lds_limit(const sr_ctx *ctx)
 {
     size_t a = ctx->prop.maxSharedMemoryPerMultiProcessor, b = ctx->prop.sharedMemPerBlock;
     return a > b ? a : b;
+}
+
+// allow `func` to be launched with `bytes` of dynamic LDS on this context's device (no-op when already granted)
+static inline int sr_grant_lds(sr_ctx *ctx, int kid, const void *func, size_t bytes)
+{
+    if (bytes <= ctx->lds_granted[kid]) return 0;
+    hipError_t e_ = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e_ != hipSuccess) {
+        sr_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) -> %s", bytes, hipGetErrorString(e_));
+        return -100 - (int)e_;
+    }
+    ctx->lds_granted[kid] = bytes;
+    return 0;
 }
 
 static inline int64_t sr_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

@@ -318,12 +318,7 @@ int sr_rotate_hist_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t 
     SR_HIP(hipMemsetAsync(h32, 0, (size_t)nV * nbins * sizeof(unsigned int), ctx->stream));
     a.edges = edges_d; a.hist_u32 = h32; a.partials = partials;
     const size_t lds = (size_t)ne * sizeof(double) + 36 * sizeof(double) + (size_t)nbins * sizeof(unsigned int);
-    static size_t configured = 0;
-    if (lds > configured) {
-        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_vechist), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-        configured = lds;
-    }
+    if (int rc = sr_grant_lds(ctx, SR_K_VECHIST, reinterpret_cast<const void *>(&k_vechist), lds)) return rc;
     hipLaunchKernelGGL(k_vechist, dim3((unsigned)a.nranges, (unsigned)nV), dim3(256), lds, ctx->stream, a);
     SR_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_vechist_finalize, dim3((unsigned)nV), dim3(256), 0, ctx->stream, h32, partials, nV, nbins,

@@ -34,11 +34,17 @@ class Context:
         self.device = int(device)
 
     def close(self):
+        """Deterministic teardown: synchronises the device and frees the context's work areas.  Call it (or use the
+        context as a `with` block) before the interpreter exits; __del__ deliberately does NOT talk to HIP once the
+        interpreter is finalising -- the runtime's own static destructors may already have run by then."""
         if getattr(self, 'h', None):
             self.lib.sr_destroy(self.h)
             self.h = None
 
     def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -73,6 +79,27 @@ class Context:
 
     def stream_destroy(self, handle):
         check(self.lib.sr_stream_destroy(self.h, ctypes.c_void_p(handle)), 'sr_stream_destroy')
+
+    def device_sync(self):
+        check(self.lib.sr_device_sync(self.h), 'sr_device_sync')
+
+    def host_alloc(self, nbytes):
+        """Page-locked host memory owned by the library (hipHostMalloc); returns the address."""
+        p = self.lib.sr_host_alloc(self.h, int(nbytes))
+        if not p:
+            raise SpinRelaxHipError('sr_host_alloc(%d) failed: %s' % (nbytes, _lib.last_error()))
+        return p
+
+    def host_free(self, addr):
+        check(self.lib.sr_host_free(self.h, ctypes.c_void_p(addr)), 'sr_host_free')
+
+    def memcpy_d2h_async(self, host_addr, dev_ptr, nbytes):
+        check(self.lib.sr_memcpy_d2h_async(self.h, ctypes.c_void_p(host_addr), ctypes.c_void_p(dev_ptr), int(nbytes)),
+              'sr_memcpy_d2h_async')
+
+    def memcpy_h2d_async(self, dev_ptr, host_addr, nbytes):
+        check(self.lib.sr_memcpy_h2d_async(self.h, ctypes.c_void_p(dev_ptr), ctypes.c_void_p(host_addr), int(nbytes)),
+              'sr_memcpy_h2d_async')
 
     def device_info(self):
         ncu = ctypes.c_int()
@@ -320,6 +347,19 @@ class Context:
 
 
 _default = {}
+
+
+def _close_default_contexts():
+    for c in list(_default.values()):
+        try:
+            c.close()
+        except Exception:
+            pass
+    _default.clear()
+
+
+import atexit as _atexit      # noqa: E402
+_atexit.register(_close_default_contexts)      # teardown while the HIP runtime is still alive, not from __del__ at exit
 
 
 def default_context(device=0):

@@ -31,6 +31,8 @@ per-batch streams.  `depth` batches are in flight at once; all per-batch device 
 The runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): two fit streams sharing a queue
 serialise their 25 ms stragglers, so set GPU_MAX_HW_QUEUES >= depth + 2 before the first HIP call (bench.py does).
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -40,13 +42,19 @@ from . import _hostmath as hm
 from . import spectral_densities as sd
 
 
-_STREAM_POOL = {}
+def _pinned_array(ctx, n, dtype):
+    """numpy array over page-locked memory owned by the library (sr_host_alloc); returns (array, address)."""
+    dtype = np.dtype(dtype)
+    nbytes = max(1, n) * dtype.itemsize
+    addr = ctx.host_alloc(nbytes)
+    buf = (ctypes.c_char * nbytes).from_address(addr)
+    return np.frombuffer(buf, dtype=dtype, count=n), addr
 
 
 class _Slot:
     """Device buffers, pinned host mirrors and stream of one in-flight batch."""
 
-    def __init__(self, dev, V, L, R, nbins, nO, Pmax, E, stream, need_fitwork, psum_len=0):
+    def __init__(self, ctx, dev, V, L, R, nbins, nO, Pmax, E, stream, need_fitwork, psum_len=0):
         f64 = dict(device=dev, dtype=torch.float64)
         i32 = dict(device=dev, dtype=torch.int32)
         Kmax = Pmax // 2
@@ -73,8 +81,11 @@ class _Slot:
                 setattr(self, name, buf[o:o + n].view(sh))
                 o += n
         self.fitwork = torch.empty((V, L), **f64) if need_fitwork else None
-        self.h_dres = torch.empty((nd,), dtype=torch.float64).pin_memory()
-        self.h_ires = torch.empty((ni,), dtype=torch.int32).pin_memory()
+        # pinned mirrors owned by the library, filled with sr_memcpy_d2h_async on the batch's stream: torch keeps no
+        # per-stream record of these copies, so the streams can be destroyed when the pipeline closes
+        self._ctx = ctx
+        self.h_dres, self._h_dres_addr = _pinned_array(ctx, nd, np.float64)
+        self.h_ires, self._h_ires_addr = _pinned_array(ctx, ni, np.int32)
         self.stream = stream
         self.front_done = None
         self.hist_done = None
@@ -83,10 +94,11 @@ class _Slot:
         self.relax_out = None
         self.result = None
 
-    def host_views(self):
-        """numpy views of the pinned mirrors (valid after `done`)."""
+    def host_results(self):
+        """COPIES of the pinned mirrors (valid after `done`): the next batch on this slot overwrites the mirrors, the
+        arrays handed to the caller stay what they were."""
         out = {}
-        for buf, layout in ((self.h_dres.numpy(), self._dlayout), (self.h_ires.numpy(), self._ilayout)):
+        for buf, layout in ((self.h_dres.copy(), self._dlayout), (self.h_ires.copy(), self._ilayout)):
             o = 0
             for name, sh in layout:
                 n = int(np.prod(sh))
@@ -94,14 +106,23 @@ class _Slot:
                 o += n
         return out
 
+    def release(self):
+        for name in ('_h_dres_addr', '_h_ires_addr'):
+            addr = getattr(self, name, None)
+            if addr:
+                self._ctx.host_free(addr)
+                setattr(self, name, None)
+        self.h_dres = self.h_ires = None
+
 
 class DevicePipeline:
     def __init__(self, ctx, device, frames, V, R, F, dt, q_rot=None, Diso=None, aniso=None, field_MHz=(600.133,),
                  zeta=0.890023, histBinX=72, listDoG=(2, 3, 5, 7, 9), csa=None, depth=1, stream=None, reserve_cus=0,
-                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None, hist_on_aux=True):
+                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None, hist_on_aux=True, v0=0):
         self.ctx = ctx
         self.dev = device
         self.frames, self.V, self.R, self.F, self.dt = frames, V, R, F, dt
+        self.v0 = int(v0)         # first vector of this shard inside the (frames, Vtot, 3) array handed to the stages
         self.L = F // 2
         self.N = R * F
         self.Npad = (frames + 63) // 64 * 64
@@ -135,7 +156,7 @@ class DevicePipeline:
         self.slots = []
         for i in range(self.depth):
             st = self.main if self.depth == 1 else self._fit_stream(resv_words)
-            self.slots.append(_Slot(device, V, self.L, R, self.nbins, len(self.listDoG), Pmax, E, st, need_fitwork,
+            self.slots.append(_Slot(ctx, device, V, self.L, R, self.nbins, len(self.listDoG), Pmax, E, st, need_fitwork,
                                     psum_len=V * R * ctx.psum_stride(F)))
         # planes: two buffers and an auxiliary stream when batches overlap -- the pack of batch k+1 and the histogram of
         # batch k (bandwidth / FP64 work) run beside the C(t) launch of batch k (FP32 issue bound) instead of in line with it
@@ -193,13 +214,11 @@ class DevicePipeline:
         return w
 
     def _borrow(self, words):
-        """CU-masked streams are never destroyed while the process lives (torch keeps per-stream bookkeeping for the
-        pinned-memory copies made on them; destroying a stream under it crashes later): closed pipelines return them
-        to a pool that the next pipeline draws from."""
-        key = (self.ctx.h if hasattr(self.ctx, 'h') else id(self.ctx), tuple(words))
-        pool = _STREAM_POOL.setdefault(key, [])
-        h = pool.pop() if pool else self.ctx.stream_create(words)
-        self._owned_streams.append((key, h))
+        """A CU-masked stream created by the library (hipExtStreamCreateWithCUMask) and wrapped for torch's event API.
+        The pipeline owns it: close() destroys it.  Nothing but kernel launches, library copies and event records /
+        waits ever happens on it, so no other runtime holds state that outlives the stream."""
+        h = self.ctx.stream_create(words)
+        self._owned_streams.append(h)
         return torch.cuda.ExternalStream(h, device=self.dev)
 
     def _masked_stream(self, bits, ncu):
@@ -211,20 +230,40 @@ class DevicePipeline:
         return self._borrow(resv_words)
 
     def close(self):
+        """Deterministic teardown: wait for the device, drop every event / stream wrapper, free the pinned mirrors and
+        destroy the CU-masked streams.  The pipeline must not be used afterwards."""
+        if getattr(self, '_closed', False):
+            return
+        self._closed = True
         torch.cuda.synchronize(self.dev)
+        self.ctx.device_sync()
         self.ctx.set_stream(0)
-        for key, h in self._owned_streams:
-            _STREAM_POOL[key].append(h)
-        self._owned_streams = []
+        for s in self.slots:
+            s.front_done = s.hist_done = s.done = None
+            s.stream = None
+            s.release()
+        self._packed_ev = [None, None]
+        self._ct_done_ev = [None, None]
+        self.main = None
+        self.aux = None
+        owned, self._owned_streams = self._owned_streams, []
+        for h in owned:
+            self.ctx.stream_destroy(h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     # ---- stages (each enqueues on the context's current stream) ----
     def stage_pack(self, vecs, soa=None):
         soa = self.soa if soa is None else soa
         if self.quat_dev is not None:
-            self.ctx.pack_soa_rot_dev(vecs.data_ptr(), self.frames, vecs.shape[1], 0, self.V, self.quat_dev.data_ptr(),
+            self.ctx.pack_soa_rot_dev(vecs.data_ptr(), self.frames, vecs.shape[1], self.v0, self.V, self.quat_dev.data_ptr(),
                                       soa.data_ptr(), self.Npad)
         else:
-            self.ctx.pack_soa_dev(vecs.data_ptr(), self.frames, vecs.shape[1], 0, self.V, soa.data_ptr(), self.Npad)
+            self.ctx.pack_soa_dev(vecs.data_ptr(), self.frames, vecs.shape[1], self.v0, self.V, soa.data_ptr(), self.Npad)
 
     def stage_ct(self, s=None, soa=None, mid_event=None, finalize=True):
         """C(t): raw sums (the dominant kernel), then mean / std over the chunks.  mid_event is recorded between the two."""
@@ -278,8 +317,8 @@ class DevicePipeline:
 
     def stage_download(self, s=None):
         s = s or self.slots[0]
-        s.h_dres.copy_(s.dres, non_blocking=True)
-        s.h_ires.copy_(s.ires, non_blocking=True)
+        self.ctx.memcpy_d2h_async(s._h_dres_addr, s.dres.data_ptr(), s.dres.numel() * 8)
+        self.ctx.memcpy_d2h_async(s._h_ires_addr, s.ires.data_ptr(), s.ires.numel() * 4)
 
     # ---- batch-level API ----
     def front(self, vecs, k, events=None, pack_next=None):
@@ -379,10 +418,10 @@ class DevicePipeline:
         return s
 
     def collect(self, s):
-        """Wait for a batch and expose its results (host views of the pinned mirrors)."""
+        """Wait for a batch and return its results (copies: they stay valid when the slot is reused)."""
         s.done.synchronize()
         s.busy = False
-        r = s.host_views()
+        r = s.host_results()
         s.result = r
         s.relax_out = r['relax']
         self.relax_out = r['relax']

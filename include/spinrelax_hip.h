@@ -241,6 +241,39 @@ int sr_jomega_relax_f64_dev(sr_ctx *, int model, const double *D, int E, const d
                             const int *nComps, int B, const double *binvecs, const double *weights, int noe_mode,
                             double *out, double *Jout, double *stats);
 
+/* ---- trajectory front end ----------------------------------------
+ * Replaces obtain_XHvecs (calculate-Ct-from-traj.py:64-86) with vecnorm_NDarray (transforms3d_supplement.py:40-52) and the
+ * MDTraj center_coordinates + superpose(ref, frame=0, atom_indices=fit_indices) step between its two calls (:466-467):
+ *   xyz       (nFrames, nAtoms, 3) float32 coordinates as MDTraj holds them (traj.xyz);
+ *   idxX/idxH nV atom indices each (the X and H selections, same order), HOST arrays in both forms;
+ *   fit_idx   nFit atom indices to superpose on, ref_xyz (nAtoms, 3) float32 reference coordinates, HOST arrays
+ *             (both may be NULL when neither vec_fit nor quat is requested);
+ *   vec_lab   (nFrames, nV, 3) float32 unit vectors (x_H - x_X)/|.| in float32 arithmetic, 0/0 -> 0: bit-identical to
+ *             the reference's numpy expression; may be NULL;
+ *   vec_fit   (nFrames, nV, 3) float32: the same bond rotated by the frame's optimal (unweighted least-squares, proper)
+ *             rotation onto the reference, float64 inside, normalised; may be NULL;
+ *   quat      (nFrames, 4) float64 (w, x, y, z), w >= 0: that rotation; may be NULL.
+ * Both outputs have the (frames, vectors, 3) layout sr_pack_soa_f32_dev / sr_ct_palmer_f32 consume. */
+int sr_xh_vectors_f32_dev(sr_ctx *, const float *xyz, int64_t nFrames, int64_t nAtoms, const int32_t *idxX_host,
+                          const int32_t *idxH_host, int nV, const int32_t *fit_idx_host, int nFit, const float *ref_xyz_host,
+                          float *vec_lab, float *vec_fit, double *quat);
+int sr_xh_vectors_f32(sr_ctx *, const float *xyz, int64_t nFrames, int64_t nAtoms, const int32_t *idxX, const int32_t *idxH,
+                      int nV, const int32_t *fit_idx, int nFit, const float *ref_xyz, float *vec_lab, float *vec_fit,
+                      double *quat);
+
+/* ---- global rotational diffusion: difference-quaternion lag correlations ----------
+ * Replaces the per-lag reductions of calculate-dq-distribution.py: obtain_self_dq (:102-109, dq_i = q_i^-1 * q_{i+d} with
+ * quat_mult_simd / quat_invert / quat_reduce_simd of transforms3d_supplement.py:163-186, 219-227), average_LegendreP1quat
+ * (:111-112), average_anisotropic_tensor (:118-126) and their *_chunk variants (:128-144) inside the main loop :554-609.
+ *   q      (N, 4) float32 orientation quaternions (w, x, y, z), e.g. the q.w..q.z columns of colvar-qorient;
+ *   lags   nlags frame offsets d (1 <= d < N), HOST array in both forms;
+ *   nchunk number of sub-chunks (>= 1); for lag d, chunk c covers samples [nb*c, min(N-d, nb*(c+1))), nb = ceil((N-d)/nchunk);
+ *   out    (nlags, nchunk, 7) float64: sums over the chunk's samples of xx, yy, zz, xy, xz, yz of v = vec(dq), then the
+ *          number of samples.  <v (x) v> = sums / count, <1 - 2|v|^2> = 1 - 2 (xx+yy+zz)/count; the whole-trajectory values
+ *          are the sums over the chunks.  Products and sums in float64 on the float32 input. */
+int sr_dq_moments_f32_dev(sr_ctx *, const float *q, int64_t N, const int32_t *lags_host, int nlags, int nchunk, double *out);
+int sr_dq_moments_f32(sr_ctx *, const float *q, int64_t N, const int32_t *lags, int nlags, int nchunk, double *out);
+
 /* ---- small device utilities ---------------------------------------------------------------
  * out[c*rows + r] = in[r*cols + c] (float64, device pointers): C(t) leaves kernel 1 as (lags, vectors)
  * like the reference, the fit reads (residues, lags). */

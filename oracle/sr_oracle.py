@@ -490,3 +490,61 @@ def new_api_eval(kind, fieldMHz, Diso, aniso, S2, consts, taus, zeta, binvecs, w
         vals[i] = v
         errs[i] = np.sqrt(np.average((x - v) ** 2.0, weights=weights[i]))
     return vals, errs
+
+
+# ----------------------------------------------------------------------------------------------
+# global rotational diffusion: calculate-dq-distribution.py
+# ----------------------------------------------------------------------------------------------
+
+def quat_mult_simd(q1, q2):
+    """transforms3d_supplement.py:163-183."""
+    q1 = np.asarray(q1, dtype=np.float64)
+    q2 = np.asarray(q2, dtype=np.float64)
+    out = np.zeros_like(q1)
+    out[..., 0] = q1[..., 0] * q2[..., 0] - np.einsum('...i,...i', q1[..., 1:4], q2[..., 1:4])
+    out[..., 1:4] = q1[..., 0, None] * q2[..., 1:4] + q2[..., 0, None] * q1[..., 1:4] + np.cross(q1[..., 1:4], q2[..., 1:4])
+    return out
+
+
+def obtain_self_dq(q, delta):
+    """calculate-dq-distribution.py:102-109: quat_reduce_simd(quat_mult_simd(quat_invert(q[:-delta]), q[delta:]))."""
+    q = np.asarray(q)
+    d = quat_mult_simd(q[:-delta] * [1.0, -1.0, -1.0, -1.0], q[delta:])          # quat_invert :185-186
+    sgn = np.sign(d[..., 0])                                                     # quat_reduce_simd :219-227, qref = (1,0,0,0)
+    sgn[sgn == 0] = 1.0
+    return d * sgn[:, None]
+
+
+def average_LegendreP1quat(vq):
+    """calculate-dq-distribution.py:111-112 AS WRITTEN: apply_along_axis(..., axis=0) hands LegendreP1_quat one COLUMN
+    (all samples of one component), so the value is mean over the three components of 1 - 2 sum_i v_ic^2, i.e.
+    1 - (2/3) sum_i |v_i|^2 -- not the sample mean of 1 - 2|v|^2.  Restated as the reference computes it."""
+    return np.mean([1.0 - 2.0 * np.sum(np.square(vq[:, c])) for c in range(3)])
+
+
+def average_anisotropic_tensor(vq):
+    """calculate-dq-distribution.py:118-126 without a frame rotation: mean of the outer products."""
+    return np.mean(np.einsum('ij,ik->ijk', vq, vq), axis=0)
+
+
+def dq_chunk_ranges(ndat, nchunk):
+    """calculate-dq-distribution.py:128-144: nblock = ceil(ndat/nchunk); chunk i = [nblock i, min(ndat, nblock (i+1)))."""
+    nblock = int(np.ceil(1.0 * ndat / nchunk))
+    return [(nblock * i, min(ndat, nblock * (i + 1))) for i in range(nchunk)]
+
+
+def dq_moments(q, lags, nchunk=1):
+    """(nlags, nchunk, 7): sums of xx yy zz xy xz yz of the vector part of dq over each chunk, and the sample count --
+    the quantity libspinrelax_hip's sr_dq_moments_f32 produces."""
+    q = np.asarray(q)
+    out = np.zeros((len(lags), nchunk, 7))
+    for k, d in enumerate(lags):
+        v = obtain_self_dq(q, int(d))[:, 1:4]
+        for c, (a, b) in enumerate(dq_chunk_ranges(v.shape[0], nchunk)):
+            w = v[a:b]
+            if w.shape[0] == 0:
+                continue
+            out[k, c, :6] = [np.sum(w[:, 0] ** 2), np.sum(w[:, 1] ** 2), np.sum(w[:, 2] ** 2), np.sum(w[:, 0] * w[:, 1]),
+                             np.sum(w[:, 0] * w[:, 2]), np.sum(w[:, 1] * w[:, 2])]
+            out[k, c, 6] = w.shape[0]
+    return out

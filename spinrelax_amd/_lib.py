@@ -75,6 +75,12 @@ SIGNATURES = {
     'sr_jomega_relax_f64_dev': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                         c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'sr_xh_vectors_f32_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                      c_void_p, c_void_p, c_void_p]),
+    'sr_xh_vectors_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
+    'sr_dq_moments_f32_dev': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p]),
+    'sr_dq_moments_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p]),
     'sr_transpose_f64_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'sr_jomega_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     'sr_jomega_relax_f64': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

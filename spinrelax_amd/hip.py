@@ -204,6 +204,44 @@ class Context:
         check(self.lib.sr_rotate_vectors_f32(self.h, _ptr(vecs), N, Vtot, v0, nV, _ptr(qq), _ptr(out)), 'sr_rotate_vectors_f32')
         return out
 
+    # ---- trajectory front end ----
+    def xh_vectors(self, xyz, indexX, indexH, fit_indices=None, ref_xyz=None, want_lab=True, want_quat=False):
+        """xyz (nFrames, nAtoms, 3) float32 -> (vec_lab, vec_fit, quat): unit X-H vectors in the lab frame, after the
+        per-frame superposition onto ref_xyz over fit_indices (None without a reference), and the rotations."""
+        xyz = _f32(xyz)
+        if xyz.ndim != 3 or xyz.shape[2] != 3:
+            raise ValueError('xyz must be (frames, atoms, 3)')
+        nF, nA, _ = xyz.shape
+        iX = np.ascontiguousarray(indexX, dtype=np.int32)
+        iH = np.ascontiguousarray(indexH, dtype=np.int32)
+        if iX.shape != iH.shape or iX.ndim != 1:
+            raise ValueError('indexX and indexH must be 1-D and of equal length')
+        nV = iX.size
+        fit = ref_xyz is not None
+        fi = np.ascontiguousarray(fit_indices, dtype=np.int32) if fit else None
+        rx = _f32(ref_xyz) if fit else None
+        if fit and rx.shape != (nA, 3):
+            raise ValueError('ref_xyz must be (atoms, 3)')
+        lab = np.empty((nF, nV, 3), dtype=np.float32) if want_lab else None
+        fitv = np.empty((nF, nV, 3), dtype=np.float32) if fit else None
+        quat = np.empty((nF, 4)) if (fit and want_quat) else None
+        check(self.lib.sr_xh_vectors_f32(self.h, _ptr(xyz), nF, nA, _ptr(iX), _ptr(iH), nV, _ptr(fi), fi.size if fit else 0,
+                                         _ptr(rx), _ptr(lab), _ptr(fitv), _ptr(quat)), 'sr_xh_vectors_f32')
+        return lab, fitv, quat
+
+    # ---- global rotational diffusion (calculate-dq-distribution.py) ----
+    def dq_moments(self, q, lags, nchunk=1):
+        """q (N, 4) float32 (w x y z); lags: frame offsets -> (nlags, nchunk, 7) float64: sums of xx yy zz xy xz yz of the
+        vector part of q_i^-1 q_{i+lag} over every chunk's samples, and the sample count."""
+        q = _f32(q)
+        if q.ndim != 2 or q.shape[1] != 4:
+            raise ValueError('q must be (N, 4)')
+        lg = np.ascontiguousarray(lags, dtype=np.int32)
+        out = np.empty((lg.size, int(nchunk), 7))
+        check(self.lib.sr_dq_moments_f32(self.h, _ptr(q), q.shape[0], _ptr(lg), lg.size, int(nchunk), _ptr(out)),
+              'sr_dq_moments_f32')
+        return out
+
     # ---- kernel 3b ----
     def expfit_resjac(self, t, y, sigma, params, want_jac=True):
         t = _f64(np.atleast_2d(t))

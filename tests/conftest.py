@@ -43,3 +43,28 @@ def relerr(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
+
+
+def files_equal_numeric(fa, fb, rtol=1e-6):
+    """Same lines and same tokens; tokens that parse as numbers may differ by rtol (a printed last digit that sat on a
+    rounding boundary).  Returns (ok, first difference or None)."""
+    with open(fa) as a, open(fb) as b:
+        la, lb = a.read().splitlines(), b.read().splitlines()
+    if len(la) != len(lb):
+        return False, 'line count %d vs %d' % (len(la), len(lb))
+    for i, (x, y) in enumerate(zip(la, lb)):
+        if x == y:
+            continue
+        tx, ty = x.split(), y.split()
+        if len(tx) != len(ty):
+            return False, 'line %d: %r vs %r' % (i + 1, x, y)
+        for u, v in zip(tx, ty):
+            if u == v:
+                continue
+            try:
+                fu, fv = float(u), float(v)
+            except ValueError:
+                return False, 'line %d: %r vs %r' % (i + 1, x, y)
+            if abs(fu - fv) > rtol * max(abs(fu), abs(fv)):
+                return False, 'line %d: %r vs %r' % (i + 1, x, y)
+    return True, None

@@ -548,3 +548,43 @@ def dq_moments(q, lags, nchunk=1):
                              np.sum(w[:, 0] * w[:, 2]), np.sum(w[:, 1] * w[:, 2])]
             out[k, c, 6] = w.shape[0]
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# trajectory front end: calculate-Ct-from-traj.py:64-86, 466-467
+# ----------------------------------------------------------------------------------------------
+
+def obtain_XHvecs(xyz, indexX, indexH):
+    """calculate-Ct-from-traj.py:82-84 on a coordinate array: take(H) - take(X), vecnorm_NDarray(axis=2); the dtype of
+    xyz (float32 for MDTraj) is kept, exactly as numpy does for the reference."""
+    v = np.take(xyz, indexH, axis=1) - np.take(xyz, indexX, axis=1)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return vecnorm_NDarray(v, axis=2)
+
+
+def kabsch_rotations(xyz, ref_xyz, fit_indices):
+    """Per-frame optimal proper rotation (3 x 3, float64) that superposes the fit atoms of every frame onto the reference
+    about their centroids: SVD form of Kabsch's algorithm -- deliberately a different algorithm from the device's
+    closed-form quaternion (Horn).  This is what MDTraj's superpose(ref, frame=0, atom_indices=...) applies
+    (calculate-Ct-from-traj.py:467; MDTraj is absent from the image, so this step is pinned by the mathematics only)."""
+    P = np.asarray(xyz, dtype=np.float64)[:, fit_indices]
+    Q = np.asarray(ref_xyz, dtype=np.float64)[fit_indices]
+    P = P - P.mean(axis=1, keepdims=True)
+    Q = Q - Q.mean(axis=0)
+    H = np.einsum('nia,ib->nab', P, Q)                       # sum_i p_i q_i^T
+    U, S, Vt = np.linalg.svd(H)
+    d = np.sign(np.linalg.det(np.einsum('nab,nbc->nac', U, Vt)))
+    D = np.zeros_like(H)
+    D[:, 0, 0] = 1.0
+    D[:, 1, 1] = 1.0
+    D[:, 2, 2] = d
+    # R = V D U^T maps p onto q
+    return np.einsum('nba,nbc,ndc->nad', Vt, D, U)
+
+
+def superposed_XHvecs(xyz, ref_xyz, fit_indices, indexX, indexH):
+    """Unit bond vectors after the superposition, float64: R_n (x_H - x_X) normalised."""
+    R = kabsch_rotations(xyz, ref_xyz, fit_indices)
+    d = (np.take(xyz, indexH, axis=1) - np.take(xyz, indexX, axis=1)).astype(np.float64)
+    r = np.einsum('nab,nvb->nva', R, d)
+    return r / np.linalg.norm(r, axis=2)[..., None], R

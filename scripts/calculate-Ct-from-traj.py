@@ -6,12 +6,14 @@ files (<o>_Ctext.dat, <o>_Ctint.dat, <o>_vecHistogram.npz | _vecPhiTheta.npz|.da
 computed on the MI355X (libspinrelax_hip.so); this script only parses arguments and moves files.
 
 Trajectory input:
-  * with MDTraj installed: -s <pdb> -f <xtc ...> exactly like the reference (vector extraction and
-    superposition are MDTraj's; reference lines 64-86, 402-491);
-  * without MDTraj (or for synthetic data): -f <file.npz|.npy> holding unit vectors of shape
-    (frames, bonds, 3) float32.  An .npz may carry `vecs` (body frame, required), `vecs_lab` (lab frame
-    for _Ctext.dat; defaults to `vecs`), `names` (resSeq per bond; default 2..V+1) and `dt` (ps; default
-    --dt).  -s is still parsed and ignored in that case.
+  * with MDTraj installed: -s <pdb> -f <xtc ...> exactly like the reference; MDTraj only reads the files and
+    resolves the atom selections, the bond vectors, the centring and the per-frame superposition (reference lines
+    64-86, 462-470) run on the GPU (csrc/sr_traj.hip);
+  * without MDTraj (or for synthetic data): -f <file.npz|.npy>.  An .npz holds either raw coordinates --
+    `xyz` (frames, atoms, 3) float32 like traj.xyz, `indexX`, `indexH` and, for the superposition, `ref_xyz` (atoms, 3)
+    and `fit_indices` -- which go through the same GPU front end, or precomputed unit vectors `vecs` (frames, bonds, 3;
+    body frame) with optional `vecs_lab` (lab frame for _Ctext.dat; defaults to `vecs`); plus `names` (resSeq per bond;
+    default 2..V+1) and `dt` (ps; default --dt).  A .npy holds unit vectors.  -s is still parsed and ignored then.
 """
 import argparse
 import os
@@ -66,8 +68,18 @@ def load_vector_files(files, default_dt):
             names, vl, d = None, v, default_dt
         else:
             z = np.load(fn, allow_pickle=True)
-            v = z['vecs']
-            vl = z['vecs_lab'] if 'vecs_lab' in z else v
+            if 'xyz' in z:
+                # raw coordinates (traj.xyz) + the index lists MDTraj's selections would give: the front end
+                # (obtain_XHvecs, centre + superpose, calculate-Ct-from-traj.py:64-86, 462-470) runs on the GPU
+                print("= = = Reading coordinate file %s ..." % fn)
+                if 'ref_xyz' in z:
+                    vl, v = hostct.superpose_XHvecs(z['xyz'], z['ref_xyz'], z['fit_indices'], z['indexX'], z['indexH'])
+                    print("= = = Molecule centered and fitted.")
+                else:
+                    v = vl = hostct.obtain_XHvecs(z['xyz'], z['indexX'], z['indexH'])
+            else:
+                v = z['vecs']
+                vl = z['vecs_lab'] if 'vecs_lab' in z else v
             names = list(z['names']) if 'names' in z else None
             d = float(z['dt']) if 'dt' in z else default_dt
         if v.ndim != 3 or v.shape[2] != 3:
@@ -92,16 +104,14 @@ def load_mdtraj(args):
         print("= = = ERROR: MDTraj is not installed; give precomputed vectors as .npy/.npz to -f instead.", file=sys.stderr)
         sys.exit(1)
 
-    def xh(traj):
+    def select(traj):
         iX = traj.topology.select(args.Xseltxt)
         iH = traj.topology.select(args.Hseltxt)
         if len(iX) == 0 or len(iH) == 0 or len(iX) != len(iH):
             print("= = = ERROR: selection text failed to find matching atoms! N(%s) = %i , N(%s) = %i"
                   % (args.Xseltxt, len(iX), args.Hseltxt, len(iH)), file=sys.stderr)
             sys.exit(1)
-        v = np.take(traj.xyz, iH, axis=1) - np.take(traj.xyz, iX, axis=1)
-        with np.errstate(divide='ignore', invalid='ignore'):
-            return np.nan_to_num(v / np.linalg.norm(v, axis=2)[..., None]).astype(np.float32)
+        return iX, iH
 
     def fit_indices(ref, fn):
         if args.fittxt == 'custom occupancy':
@@ -121,10 +131,11 @@ def load_mdtraj(args):
         for trj in chunks:
             names = [trj.topology.atom(k).residue.resSeq for k in trj.topology.select(args.Hseltxt)]
             d = trj.timestep
-            l.append(xh(trj))
-            trj.center_coordinates()
-            trj.superpose(ref, frame=0, atom_indices=fi)
-            b.append(xh(trj))
+            # MDTraj reads the file and resolves the selections; vectors, centring and superposition run on the GPU
+            iX, iH = select(trj)
+            vl, vb = hostct.superpose_XHvecs(trj.xyz, ref.xyz[0], fi, iX, iH)
+            l.append(vl)
+            b.append(vb)
         if resXH is None:
             resXH, dt = names, d
         lab.append(np.concatenate(l, axis=0))

@@ -154,3 +154,30 @@ def detumble_vectors(vecs_lab, q_orient, ctx=None):
                          % (q.shape, np.shape(vecs_lab)[0]))
     q[:, 1:] *= -1.0
     return rotate_vector_simd(vecs_lab, q, ctx=ctx).astype(np.float32)
+
+
+def obtain_XHvecs(xyz, indexX, indexH, ctx=None, bSuppressPrint=False):
+    """obtain_XHvecs (calculate-Ct-from-traj.py:64-86) on a coordinate array instead of an MDTraj trajectory: xyz is
+    traj.xyz (frames, atoms, 3) float32, indexX / indexH what topology.select() returned for the X and H selections.
+    Unit vectors (x_H - x_X)/|x_H - x_X|, float32, 0/0 -> 0, computed on the GPU (bit-identical to the numpy expression)."""
+    if not bSuppressPrint:
+        print("= = = Obtaining XH-vectors from trajectory...")
+    numX, numH = len(indexX), len(indexH)
+    if numX == 0 or numH == 0:
+        print("= = = ERROR: selection text failed to find atoms!")
+        print("     ....debug: N(X) = %i , N(H) = %i" % (numX, numH))
+        sys.exit(1)
+    if numX != numH:
+        print("= = = ERROR: selection text found different number of atoms!")
+        print("     ....debug: N(X) = %i , N(H) = %i" % (numX, numH))
+        sys.exit(1)
+    lab, _, _ = _ctx(ctx).xh_vectors(xyz, indexX, indexH)
+    return lab
+
+
+def superpose_XHvecs(xyz, ref_xyz, fit_indices, indexX, indexH, ctx=None, want_quat=False):
+    """The reference's two obtain_XHvecs calls around trj.center_coordinates(); trj.superpose(ref, frame=0,
+    atom_indices=fit_indices) (calculate-Ct-from-traj.py:462-470) in one pass over the coordinates on the GPU:
+    returns (vecXH lab frame, vecXHfit after the per-frame least-squares superposition [, rotation quaternions])."""
+    lab, fitv, quat = _ctx(ctx).xh_vectors(xyz, indexX, indexH, fit_indices=fit_indices, ref_xyz=ref_xyz, want_quat=want_quat)
+    return (lab, fitv, quat) if want_quat else (lab, fitv)

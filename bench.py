@@ -12,16 +12,29 @@ model-order search -> J(omega)/R1/R2/NOE/rho, and for N > 1 the RCCL all-gather 
 (SURVEY.md section 8(e)).  Workload: BASELINE.json configs[2] (100 000 frames x 512 vectors, 2 048 lags,
 axisymmetric D, q_ext rotation + vecHistogram) PER GPU -- the configuration the north-star quotes its
 scaling on; weak scaling: every rank owns its own 512 vectors (rank r = vectors 512 r .. 512 r + 511
-of one synthetic trajectory).  `value` = exact triples of all ranks / wall time of a step.
+of one synthetic trajectory).  `value` = exact triples of all ranks / wall time of a step, with `--depth` batches in
+flight (throughput); `latency_ms` = one batch alone, start to results on the host.
 
-One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel (the C(t) kernel): 8 flop x exact triples per launch / mean launch time
-                (HIP events on the launch stream, inside the timed region) against the 157.3 TFLOP/s
-                FP32 vector peak (= the FP32 MFMA peak) of MI355X_MICROARCH.md; SURVEY.md section 8(d).
-                Since the kernel computes the same sums by FFT (k_ct_fft, 4 % of the direct flop, in float64)
-                `roofline.executed` gives the executed work against the FP64 vector peak as well.
-  cpu_baseline  the reference's algorithm (per-lag float32 numpy einsum, calculate-Ct-from-traj.py:222-228,
-                restated in oracle/sr_oracle.py) timed on this host on a bounded sample (rank 0, N = 1).
+One JSON line is printed by rank 0 (contract in the task statement) with extra objects:
+  kernels       one entry per kernel of a step, every `frac` a fraction of a bound THAT kernel can reach, from what it
+                executes:  k_ct_fft -- executed float64 flop / duration against the FP64 vector peak;  k_ct_palmer (the
+                direct formulation, timed alone as a second line) -- 8 flop x exact triples against the FP32 vector peak;
+                k_vechist, k_pack_soa -- algorithmic bytes / duration against the HBM peak;  k_order_search -- residues/s,
+                evaluations/s and the executed float64 flop (PMC count of the committed profile: the data are
+                deterministic) / duration against the FP64 vector peak.  Durations: `in_pipeline_ms` from HIP events placed
+                around the launch on the stream it runs on, inside the timed region; `alone_ms` the same launch by itself
+                on the whole chip after the timed region; `cu_ms_per_batch` = 256 CUs x the time a batch's worth of that
+                kernel takes when the chip is saturated with it (the fit: 8 batches' residues, longest first, in one launch / 8).
+  roofline      the `kernels` entry with the largest cu_ms_per_batch (the kernel that occupies most of the chip), in the
+                contract's shape {bound, achieved, peak, unit, frac, traffic}; `direct_equivalent` keeps the reference
+                formulation's 8 flop / 24 B per triple over the C(t) kernel's duration for comparison only.
+  cpu_baseline  the reference's algorithm on this host (rank 0, N = 1) on a bounded sample of the SAME path the GPU value
+                covers: per-lag float32 numpy einsum C(t) (calculate-Ct-from-traj.py:222-228), scipy curve_fit model-order
+                search (fitting_Ct_functions.py:278-345), per-residue J(w)/R1/R2/NOE over the 2 592 bins
+                (calculate-relaxations-from-Ct.py:158-176), restated in oracle/sr_oracle.py -- 1 thread like the reference;
+                plus the CPU-FFT formulation (like-for-like with k_ct_fft) and the OpenMP C loop on all cores.
+Peaks: FP32 vector 157.3 TFLOP/s and HBM 8 TB/s from /opt/skills/guides/MI355X_MICROARCH.md; FP64 vector 78.6 TFLOP/s from
+the AMD Instinct MI355X data sheet (peak double-precision vector; = half the FP32 vector rate of the guide's table).
 """
 import argparse
 import json
@@ -40,23 +53,29 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '10')
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector = FP32 matrix peak
-PEAK_FP64_TFLOPS = 78.6           # MI355X_MICROARCH.md: FP64 vector
-PEAK_HBM_GBS = 8000.0
+PEAK_FP64_TFLOPS = 78.6           # AMD Instinct MI355X data sheet: peak FP64 vector (half the FP32 vector rate)
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+N_CU = 256
 
 
-def measured_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, produced by
-    scripts/make_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command)."""
+def committed_profile():
+    """Per-kernel figures of the committed rocprofv3 PMC passes (profiles/, scripts/make_profiles.py): HBM bytes per
+    launch and, for the fit kernel, executed float64 flop per launch.  NOT measured in this run (PMC counters need
+    rocprofv3); the inputs are deterministic, so the per-launch counts carry over."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_cfg3_hbm_counters.json')))
     if not files:
-        return None, None
+        return {}, None
     with open(files[-1]) as fp:
         d = json.load(fp)
-    for k, v in d.get('kernels', {}).items():
-        if k.startswith(kernel_prefix):
-            return v['hbm_bytes_corrected'], os.path.relpath(files[-1], ROOT)
-    return None, None
+    return d.get('kernels', {}), os.path.relpath(files[-1], ROOT)
+
+
+def prof_entry(prof, prefix):
+    for k, v in prof.items():
+        if k.startswith(prefix):
+            return v
+    return None
 
 
 def parse():
@@ -75,27 +94,80 @@ def parse():
     ap.add_argument('--ct-fft', type=int, default=-1, help='1/0: FFT formulation of the C(t) kernel (-1 = library default)')
     ap.add_argument('--depth', type=int, default=6, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-profile', action='store_true', help='skip the per-kernel alone / saturated timings after the timed region (the `kernels` entries then only carry in-pipeline durations)')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
     ap.add_argument('--all-ranks-on-device0', action='store_true', help='rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)')
-    ap.add_argument('--stage-breakdown', action='store_true', help='after the timed loop, print a synchronised per-stage wall-time breakdown to stderr (diagnostic)')
-    ap.add_argument('--cpu-sample-vectors', type=int, default=8)
+    ap.add_argument('--cpu-sample-vectors', type=int, default=4, help='vectors of the 1-thread reference-equivalent CPU sample')
+    ap.add_argument('--cpu-allcore-vectors', type=int, default=64, help='vectors of the all-core / CPU-FFT samples (>= 64: not cache-resident)')
     return ap.parse_args()
 
 
-def cpu_baseline(vecs_sample, s):
-    """Reference-equivalent CPU path for C(t) on a bounded sample; returns the cpu_baseline object."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): the reference's algorithm for the whole path on a bounded sample
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(vecs_host, s, cfg, nv1, nvall):
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import sr_oracle as o
-    v4 = vecs_sample[: s['N']].reshape(s['R'], s['F'], -1, 3)
-    triples = o.exact_triples(s['R'], s['F'], v4.shape[2])
+    from spinrelax_amd import synth
+    R, F, N = s['R'], s['F'], s['N']
+    v4 = vecs_host[:N, :nv1].reshape(R, F, nv1, 3)
+    triples = o.exact_triples(R, F, nv1)
+    stages = {}
     t0 = time.time()
-    o.calculate_Ct_Palmer(v4, dtype=np.float32)          # same numpy calls as the reference, float32, 1 thread
-    dt = time.time() - t0
-    out = dict(value=triples / dt, unit='triples/s', cores=1, kind='port',
-               sample='C(t) stage only: %d chunks x %d frames x %d vectors (%.3g exact triples) of the same '
-                      'trajectory, numpy float32 per-lag einsum as calculate-Ct-from-traj.py:222-228, %.1f s'
-                      % (s['R'], s['F'], v4.shape[2], triples, dt))
-    # the same algorithm as a multi-threaded C loop (oracle/ct_palmer_oracle.c), all host cores
+    Ct, dCt = o.calculate_Ct_Palmer(v4, dtype=np.float32)          # same numpy calls as the reference, float32, 1 thread
+    stages['ct_s'] = time.time() - t0
+    aniso = cfg == 3
+    hist = edges = None
+    if aniso:
+        t0 = time.time()
+        rot = o.rotate_vector_simd(vecs_host[:N, :nv1], np.array(synth.Q_EXT))
+        hist, edges = o.lambert_histogram(rot)
+        del rot
+        stages['rotate_hist_s'] = time.time() - t0
+    t0 = time.time()
+    t = o.calculate_dt(s['dt'], s['tau_memory'])
+    fits = []
+    for i in range(nv1):
+        best, _ = o.optimised_curve_fitting(t, Ct[:, i].astype(np.float64), dCt[:, i].astype(np.float64))
+        fits.append(best)
+    stages['fit_s'] = time.time() - t0
+    t0 = time.time()
+    idx = [i for i, f in enumerate(fits) if f is not None]
+    if idx:
+        B0 = o.B0_from_Hz(synth.FIELD_MHZ * 1e6)
+        S2 = [synth.ZETA * fits[i]['S2'] for i in idx]
+        C = [synth.ZETA * np.asarray(fits[i]['C']) for i in idx]
+        tau = [np.asarray(fits[i]['tau']) for i in idx]
+        if aniso:
+            Dpar, Dperp = o.symmtop_from_iso(synth.DISO, synth.DANI)
+            bv, w = o.convert_LambertCylindricalHist_to_vecs(hist, edges)
+            o.obtain_R1R2NOErho('rigid_symmtop', (Dpar, Dperp), B0, S2, C, tau, vecXH=[bv[i] for i in idx], weights=[w[i] for i in idx])
+        else:
+            o.obtain_R1R2NOErho('rigid_sphere', synth.DISO, B0, S2, C, tau)
+    stages['relax_s'] = time.time() - t0
+    total = sum(stages.values())
+    out = dict(value=triples / total, unit='triples/s', cores=1, kind='port',
+               sample='whole path (C(t) float32 per-lag einsum + %sscipy curve_fit order search + J(w)/R1/R2/NOE) on %d of the '
+                      'vectors, all %d chunks x %d frames (%.3g exact triples), numpy/scipy as the reference calls them, 1 thread, %.1f s'
+                      % ('rotation + histogram + ' if aniso else '', nv1, R, F, triples, total),
+               stages_s={k: round(v, 3) for k, v in stages.items()},
+               ct_only_triples_per_s=triples / stages['ct_s'])
+    # like-for-like partner of k_ct_fft: the same Wiener-Khinchin formulation on the CPU (numpy FFT, 1 thread)
+    nva = min(nvall, vecs_host.shape[1])
+    v4a = vecs_host[:N, :nva].reshape(R, F, nva, 3)
+    tra = o.exact_triples(R, F, nva)
+    try:
+        nf = min(nva, 16)
+        t0 = time.time()
+        o.calculate_Ct_fft(v4a[:, :, :nf])
+        dtf = time.time() - t0
+        out['cpu_fft_formulation'] = dict(value=o.exact_triples(R, F, nf) / dtf, unit='triples/s', cores=1,
+                                          kind='port (float64 FFT autocorrelations, numpy.fft; C(t) stage only)',
+                                          sample='%d vectors, %.2f s' % (nf, dtf))
+    except Exception as exc:
+        out['cpu_fft_formulation'] = dict(error=str(exc))
+    # the reference's per-lag streaming algorithm as a multi-threaded C loop (oracle/ct_palmer_oracle.c), all host cores,
+    # on a sample that does not fit the caches (>= 64 vectors: 75 MB)
     try:
         import ctypes
         import subprocess
@@ -104,19 +176,29 @@ def cpu_baseline(vecs_sample, s):
             subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'libsr_oracle.so'],
                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         lib = ctypes.CDLL(so)
-        v4c = np.ascontiguousarray(v4, dtype=np.float32)
-        L = s['F'] // 2
-        Ct = np.empty((L, v4c.shape[2]), dtype=np.float32)
-        dCt = np.empty_like(Ct)
+        v4c = np.ascontiguousarray(v4a, dtype=np.float32)
+        L = F // 2
+        Cc = np.empty((L, nva), dtype=np.float32)
+        dCc = np.empty_like(Cc)
         t0 = time.time()
-        lib.sr_oracle_ct_palmer_f32_stream(v4c.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(s['R']), ctypes.c_int64(s['F']),
-                                           ctypes.c_int64(v4c.shape[2]), Ct.ctypes.data_as(ctypes.c_void_p),
-                                           dCt.ctypes.data_as(ctypes.c_void_p))
+        lib.sr_oracle_ct_palmer_f32_stream(v4c.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(R), ctypes.c_int64(F),
+                                           ctypes.c_int64(nva), Cc.ctypes.data_as(ctypes.c_void_p),
+                                           dCc.ctypes.data_as(ctypes.c_void_p))
         dt2 = time.time() - t0
-        out['all_cores'] = dict(value=triples / dt2, cores=os.cpu_count(), kind='port (C + OpenMP, same per-lag streaming algorithm)')
+        out['all_cores'] = dict(value=tra / dt2, unit='triples/s', cores=os.cpu_count(),
+                                kind='port (C + OpenMP, same per-lag streaming algorithm; C(t) stage only)',
+                                sample='%d vectors (%.0f MB, not cache-resident), %.2f s' % (nva, v4c.nbytes / 1e6, dt2))
     except Exception as exc:                                 # the extra figure is optional
         out['all_cores'] = dict(error=str(exc))
     return out
+
+
+def fft_exec_flop(s, V):
+    """executed float64 work of k_ct_fft per launch: 4 complex M-point transforms (5 M log2 M flop each), the power
+    spectra of 3 packed pairs (12 flop per frequency each) and the 6 products per frame, per (chunk, vector)."""
+    need = s['F'] + s['L']
+    M = 2048 if need <= 2048 else (4096 if need <= 4096 else (6144 if need <= 6144 else 8192))
+    return M, s['R'] * V * (4 * 5 * M * np.log2(M) + 3 * 12 * M + 6 * s['F'])
 
 
 def main():
@@ -163,10 +245,10 @@ def main():
     if args.ct_fft >= 0:
         ctx.set_option('ct_fft', args.ct_fft)
     triples = synth.exact_triples(s['R'], s['F'], V)
-    pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], q_rot=q, Diso=synth.DISO, aniso=aniso,
-                          field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA, depth=args.depth,
+    pkw = dict(q_rot=q, Diso=synth.DISO, aniso=aniso, field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA)
+    pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], depth=args.depth,
                           stream=torch.cuda.Stream(device=dev), reserve_cus=args.reserve_cus,
-                          fits_on_reserved_only=bool(args.fits_on_reserved_only), hist_on_aux=not args.hist_on_main)
+                          fits_on_reserved_only=bool(args.fits_on_reserved_only), hist_on_aux=not args.hist_on_main, **pkw)
     stream = pipe.main
     if args.dev_skip_fits:
         pipe.stage_fit = lambda s=None: None
@@ -211,7 +293,8 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
         run_batches(args.warmup)
-        events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+        nfev0 = pipe.nfev_total
+        events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -224,90 +307,208 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
 
-    if args.stage_breakdown and rank == 0:
-        with torch.cuda.stream(stream):
-            names = ['pack', 'ct', 'hist', 'transpose', 'fit', 'relax', 'download']
-            s0 = pipe.slots[0]
-            ctx.set_stream(stream.cuda_stream)
-            fns = [lambda: pipe.stage_pack(vecs), lambda: pipe.stage_ct(s0), lambda: pipe.stage_hist(s0),
-                   lambda: pipe.stage_transpose(s0), lambda: pipe.stage_fit(s0), lambda: pipe.stage_relax(s0),
-                   lambda: pipe.stage_download(s0)]
-            acc = {n: 0.0 for n in names}
-            for _ in range(3):
-                for n, fn in zip(names, fns):
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    fn()
-                    torch.cuda.synchronize()
-                    acc[n] += (time.perf_counter() - t1) / 3
-            print('stage wall ms:', {k: round(v * 1e3, 3) for k, v in acc.items()}, 'fit nfev total', pipe.nfev_total, file=sys.stderr)
-            for nP, nf in pipe.nfev_last.items():
-                print('  order %d: %d fits, nfev mean %.1f median %d p95 %d max %d, >=%d: %d' % (nP, nf.size, nf.mean(), np.median(nf), np.percentile(nf, 95), nf.max(), 100 * nP, int((nf >= 100 * nP).sum())), file=sys.stderr)
-
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ct_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    hist_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
+    hist_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in events])) if q is not None else None
+    fit_ms = None if args.dev_skip_fits else float(np.mean([e[4].elapsed_time(e[5]) for e in events]))
+    best = pipe.fit_best
+    nfev_step = (pipe.nfev_total - nfev0) / max(1, args.steps)
+    depth_used, reserve_used = pipe.depth, pipe.reserve_cus
+    listDoG = pipe.listDoG
+    del events, gbuf
+    pipe.close()
+
+    # ---- after the timed region: one batch at a time on the whole chip -- latency, every kernel alone, the fit saturated ----
+    alone, latency = {}, None
+    if rank == 0 and not args.no_kernel_profile and not args.dev_skip_fits:
+        p1 = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], depth=1, stream=torch.cuda.Stream(device=dev), **pkw)
+        st1 = p1.main
+        p1.step(vecs)
+        lat = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            p1.step(vecs)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        latency = dict(min=min(lat), mean=float(np.mean(lat)), note='one batch alone on the whole chip, vectors in HBM -> R1/R2/NOE table on the host')
+        s0 = p1.slots[0]
+        ctx.set_stream(st1.cuda_stream)
+
+        def timed(fn, reps=3):
+            out = []
+            with torch.cuda.stream(st1):
+                for _ in range(reps):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(st1)
+                    fn()
+                    b.record(st1)
+                    b.synchronize()
+                    out.append(a.elapsed_time(b))
+            return float(min(out))
+
+        alone['pack'] = timed(lambda: p1.stage_pack(vecs))
+        alone['ct'] = timed(lambda: p1.stage_ct(s0, finalize=False))
+        alone['ct_finalize'] = timed(lambda: p1.stage_ct_finalize(s0))
+        if q is not None:
+            alone['hist'] = timed(lambda: p1.stage_hist(s0))
+        alone['transpose'] = timed(lambda: p1.stage_transpose(s0))
+        alone['fit'] = timed(lambda: p1.stage_fit(s0), reps=2)
+        alone['relax'] = timed(lambda: p1.stage_relax(s0))
+        # the direct formulation of kernel 1 (the north-star's named kernel) as a second line
+        if 1024 < s['F'] + s['L'] <= 8192 and args.ct_fft != 0:
+            ctx.set_option('ct_fft', 0)
+            alone['ct_direct'] = timed(lambda: p1.stage_ct(s0, finalize=False), reps=2)
+            ctx.set_option('ct_fft', 1)
+            with torch.cuda.stream(st1):
+                p1.stage_ct(s0)                 # restore the slot's sums / C(t) from the production kernel
+        # The model-order search with the chip saturated: 8 batches' residues in ONE launch, the expensive residues first
+        # (sorted by the evaluations they needed in the batch above).  A lone launch lasts as long as its slowest residue
+        # (~10 ms for one 286-evaluation fit); with several batches in flight that tail overlaps the next batches' work,
+        # and what a batch costs the chip is (sum of the residues' solve times) / (resident workgroups) -- which is what
+        # this launch measures, because longest-first dispatch leaves no tail.
+        K = 8
+        f64 = dict(device=dev, dtype=torch.float64)
+        i32 = dict(device=dev, dtype=torch.int32)
+        nO, Pmax, Kmax = len(listDoG), max(listDoG), max(listDoG) // 2
+        cost = s0.result['nfev'].sum(axis=0)
+        order = torch.from_numpy(np.argsort(-cost, kind='stable').copy()).to(dev)
+        torch.cuda.synchronize()
+        tK = p1.t_dev.repeat(K, 1)
+        yK, dK = s0.CtT[order].repeat_interleave(K, dim=0), s0.dCtT[order].repeat_interleave(K, dim=0)
+        oK = dict(popt=torch.empty((nO, K * V, Pmax), **f64), dP=torch.empty((nO, K * V, Pmax), **f64), chisq=torch.empty((nO, K * V), **f64),
+                  status=torch.empty((nO, K * V), **i32), nfev=torch.empty((nO, K * V), **i32), best=torch.empty((K * V,), **i32),
+                  S2=torch.empty((K * V,), **f64), C=torch.empty((K * V, Kmax), **f64), tau=torch.empty((K * V, Kmax), **f64),
+                  chi=torch.empty((K * V,), **f64), Kc=torch.empty((K * V,), **i32), work=torch.empty((K * V, s['L']), **f64))
+        torch.cuda.synchronize()
+
+        def fitK():
+            ctx.order_search_dev(tK.data_ptr(), yK.data_ptr(), dK.data_ptr(), K * V, s['L'], listDoG, p1.tau_guess.data_ptr(), 1,
+                                 p1.tau_max, p1.chi_thr, oK['popt'].data_ptr(), oK['dP'].data_ptr(), oK['chisq'].data_ptr(),
+                                 oK['status'].data_ptr(), oK['nfev'].data_ptr(), oK['best'].data_ptr(), oK['S2'].data_ptr(),
+                                 oK['C'].data_ptr(), oK['tau'].data_ptr(), oK['chi'].data_ptr(), oK['Kc'].data_ptr(),
+                                 work_ptr=oK['work'].data_ptr())
+        alone['fit_saturated_per_batch'] = timed(fitK, reps=2) / K
+        torch.cuda.synchronize()
+        del tK, yK, dK, oK
+        p1.close()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = triples * world / (elapsed / args.steps)
-        achieved = 8.0 * triples / (ct_ms * 1e-3) / 1e12
         use_fft = (args.ct_fft != 0) and 1024 < s['F'] + s['L'] <= 8192
         kname = 'k_ct_fft' if use_fft else 'k_ct_palmer'
-        traffic, traffic_src = measured_traffic(kname) if cfg == 3 and V == 512 else (None, None)
+        prof, prof_src = committed_profile() if cfg == 3 and V == 512 else ({}, None)
+        N, R, L = s['N'], s['R'], s['L']
+        kernels = {}
+
+        def entry(name, bound, work, unit_scale, peak, unit, t_pipe, t_alone, t_sat=None, **extra):
+            """work per launch (flop or bytes); achieved = work / duration; frac against `peak`."""
+            e = dict(bound=bound, work_per_launch=float(work), peak=peak, unit=unit)
+            if t_pipe:
+                e['in_pipeline_ms'] = t_pipe
+                e['achieved'] = work / (t_pipe * 1e-3) / unit_scale
+                e['frac'] = e['achieved'] / peak
+            if t_alone:
+                e['alone_ms'] = t_alone
+                e['achieved_alone'] = work / (t_alone * 1e-3) / unit_scale
+                e['frac_alone'] = e['achieved_alone'] / peak
+                if 'achieved' not in e:
+                    e['achieved'], e['frac'] = e['achieved_alone'], e['frac_alone']
+            sat = t_sat if t_sat else t_alone
+            if sat:
+                e['cu_ms_per_batch'] = sat * N_CU
+            pe = prof_entry(prof, name)
+            e['traffic'] = pe['hbm_bytes_corrected'] if pe else None
+            e['traffic_note'] = ('HBM bytes per launch (PMC 2*FETCH_SIZE + WRITE_SIZE) from the committed profile %s -- '
+                                 'not measured in this run' % prof_src) if pe else 'no committed PMC profile for this kernel / configuration'
+            e.update(extra)
+            kernels[name] = e
+            return e
+
         if use_fft:
-            need = s['F'] + s['L']
-            M = 2048 if need <= 2048 else (4096 if need <= 4096 else (6144 if need <= 6144 else 8192))
-            # executed float64 work of the FFT formulation: 4 complex M-point transforms (5 M log2 M flop each), the
-            # power spectra of 3 packed pairs (12 flop per frequency each) and the 6 products per frame
-            exec_flop = s['R'] * V * (4 * 5 * M * np.log2(M) + 3 * 12 * M + 6 * s['F'])
-            executed = {'formulation': 'Wiener-Khinchin: 6 float64 autocorrelations by FFT, whole %d-point transform resident in LDS' % M,
-                        'flop_per_launch': float(exec_flop), 'fraction_of_direct_flop': float(exec_flop / (8.0 * triples)),
-                        'achieved': float(exec_flop / (ct_ms * 1e-3) / 1e12), 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s (float64 vector)',
-                        'frac': float(exec_flop / (ct_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS),
-                        'note': 'latency-bound: one 4-wave workgroup per CU (114-152 KB LDS, ~450 registers per lane)'}
+            M, xflop = fft_exec_flop(s, V)
+            entry('k_ct_fft', 'valu-fp64 (float64 vector FMA; latency- and LDS-exchange-limited)', xflop, 1e12, PEAK_FP64_TFLOPS, 'TFLOP/s',
+                  ct_ms, alone.get('ct'), formulation='Wiener-Khinchin: 6 float64 autocorrelations by FFT, whole %d-point transform resident in LDS' % M,
+                  algorithmic_bytes=12 * N * V + 8 * R * L * V,
+                  note='in the pipeline the kernel is confined to %d of %d CUs' % (N_CU - reserve_used, N_CU))
+            if alone.get('ct_direct'):
+                entry('k_ct_palmer', 'valu-fp32 (non-MFMA vector FMA; FP32 MFMA peak is the same)', 8.0 * triples, 1e12, PEAK_FP32_TFLOPS, 'TFLOP/s',
+                      None, alone['ct_direct'], formulation='direct shifted products, 8 flop per (frame, vector, lag) triple (SURVEY 8(d)); second line, timed alone',
+                      algorithmic_bytes=12 * N * V + 8 * R * L * V)
         else:
-            executed = {'formulation': 'direct shifted products, float32 FMA', 'flop_per_launch': 8.0 * triples, 'fraction_of_direct_flop': 1.0,
-                        'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s (float32 vector)', 'frac': achieved / PEAK_FP32_TFLOPS}
-        best, _ = pipe.fit_best, None
+            entry('k_ct_palmer', 'valu-fp32 (non-MFMA vector FMA; FP32 MFMA peak is the same)', 8.0 * triples, 1e12, PEAK_FP32_TFLOPS, 'TFLOP/s',
+                  ct_ms, alone.get('ct'), formulation='direct shifted products, 8 flop per triple', algorithmic_bytes=12 * N * V + 8 * R * L * V)
+        if q is not None:
+            entry('k_vechist', 'hbm', 12.0 * N * V + 8.0 * V * 2592, 1e9, PEAK_HBM_GBS, 'GB/s', hist_ms, alone.get('hist'),
+                  formulation='one pass: rotation + Lambert histogram + mean vector + S2 sums; bytes = 12 N V + 8 V 2592 (SURVEY 8(d))')
+        if alone.get('pack'):
+            entry('k_pack_soa', 'hbm', 24.0 * s['frames'] * V, 1e9, PEAK_HBM_GBS, 'GB/s', None, alone['pack'],
+                  formulation='frame-major -> per-vector planes: 12 B read + 12 B written per (frame, vector)')
+        if fit_ms is not None:
+            pe = prof_entry(prof, 'k_order_search')
+            fflop = pe.get('fp64_flop_per_launch') if pe else None
+            sat = alone.get('fit_saturated_per_batch')
+            tref = sat or alone.get('fit') or fit_ms
+            e = dict(bound='valu-fp64 issue + latency (one workgroup per residue, hundreds of dependent solver iterations)',
+                     in_pipeline_ms=fit_ms, alone_ms=alone.get('fit'), saturated_ms_per_batch=sat,
+                     cu_ms_per_batch=sat * N_CU if sat else None, residues=V, evaluations_per_batch=nfev_step,
+                     residues_per_s=V / (tref * 1e-3), evaluations_per_s=nfev_step / (tref * 1e-3),
+                     peak=PEAK_FP64_TFLOPS, unit='TFLOP/s',
+                     note='rates over the saturated duration (8 batches, longest residues first, in one launch / 8): the time the chip needs per batch when '
+                          'it is full of fits; a lone launch lasts as long as its slowest residue (alone_ms)')
+            if fflop:
+                e['work_per_launch'] = float(fflop)
+                e['achieved'] = fflop / (tref * 1e-3) / 1e12
+                e['frac'] = e['achieved'] / PEAK_FP64_TFLOPS
+                e['work_note'] = 'executed float64 flop per launch from the PMC pass of the committed profile %s (deterministic data)' % prof_src
+            else:
+                e['achieved'] = e['frac'] = None
+                e['work_note'] = 'no committed float64-instruction PMC pass: flop rate not stated'
+            e['traffic'] = pe['hbm_bytes_corrected'] if pe else None
+            e['traffic_note'] = 'from the committed profile %s -- not measured in this run' % prof_src if pe else None
+            e['algorithmic_bytes'] = 24 * V * L + 1024 * V
+            kernels['k_order_search'] = e
+        # the kernel that occupies most of the chip per batch
+        ranked = sorted(((v.get('cu_ms_per_batch') or 0.0, k) for k, v in kernels.items() if not (k == 'k_ct_palmer' and use_fft)), reverse=True)
+        top = ranked[0][1] if ranked and ranked[0][0] > 0 else kname
+        tk = kernels[top]
+        roofline = {'kernel': top, 'bound': tk['bound'], 'achieved': tk.get('achieved'), 'peak': tk['peak'], 'unit': tk['unit'],
+                    'frac': tk.get('frac'), 'traffic': tk.get('traffic'), 'traffic_note': tk.get('traffic_note'),
+                    'selection': 'largest cu_ms_per_batch among the kernels of a step: ' + ', '.join('%s %.0f' % (k, c) for c, k in ranked),
+                    'kernel_ms': tk.get('saturated_ms_per_batch') or tk.get('in_pipeline_ms') or tk.get('alone_ms'),
+                    'direct_equivalent': {'note': 'for comparison only, NOT a roofline: the reference formulation (8 flop, 24 B streamed per triple) '
+                                                  'credited to the duration of the kernel that computes C(t)',
+                                          'kernel': kname, 'kernel_ms': ct_ms, 'TFLOPs_equiv': 8.0 * triples / (ct_ms * 1e-3) / 1e12,
+                                          'streaming_equiv_GBps': 24.0 * triples / (ct_ms * 1e-3) / 1e9}}
         res = {
             'metric': 'frame-vector-lag triples/s, C(t) + fit + R1/R2/NOE pipeline',
             'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': ms_per_step, 'latency_ms': latency, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64 (C(t) by FFT on f32 inputs; histogram, fit, J(w), R1/R2/NOE)' if use_fft else 'f32 dot products / f64 accumulation (C(t)); f64 (histogram, fit, J(w), R1/R2/NOE)',
             'data': 'synthetic',
             'config': {'workload': 'BASELINE cfg%d per GPU: %d frames x %d vectors, %d chunks x %d frames, %d lags, '
                                    '%s, fits 2/3/5/7/9 params, 1 field' % (cfg, s['frames'], V, s['R'], s['F'], s['L'],
                                                                            'axisymmetric D + q_ext + 72x36 histogram' if cfg == 3 else 'isotropic D'),
-                       'vectors_per_gpu': V, 'exact_triples_per_gpu': triples, 'sharding': 'vectors (no data-path collective; all-gather of results)', 'batches_in_flight': pipe.depth, 'cus_reserved_for_fits': pipe.reserve_cus},
-            'roofline': {'bound': 'valu-fp32 (non-MFMA vector FMA; FP32 MFMA peak is the same 157.3): ALGORITHMIC flop of the path, 8 per triple (SURVEY 8(d)), '
-                                  'over the measured duration of the kernel that computes C(t) -- see `executed` for what that kernel actually executes',
-                         'kernel': kname,
-                         'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS,
-                         'traffic': traffic, 'traffic_unit': 'bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)', 'traffic_source': traffic_src,
-                         'algorithmic_bytes': 12 * s['N'] * V + 8 * s['R'] * s['L'] * V, 'kernel_ms': ct_ms, 'flop_per_triple': 8,
-                         'streaming_equiv_GBps': 24.0 * triples / (ct_ms * 1e-3) / 1e9,
-                         'streaming_equiv_frac_of_hbm': 24.0 * triples / (ct_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                         'executed': executed},
-            'stages_ms': {'ct_palmer': ct_ms, 'rotate_hist': hist_ms,
-                          'rotate_hist_GBps': 12.0 * s['N'] * V / (hist_ms * 1e-3) / 1e9},
-            'fit': {'residues': V, 'selected_orders': {str(pipe.listDoG[j]): int((best == j).sum()) for j in range(len(pipe.listDoG))},
-                    'unfitted': int((best < 0).sum())},
+                       'vectors_per_gpu': V, 'exact_triples_per_gpu': triples, 'sharding': 'vectors (no data-path collective; all-gather of results)',
+                       'batches_in_flight': depth_used, 'cus_reserved_for_fits': reserve_used},
+            'roofline': roofline,
+            'kernels': kernels,
+            'stages_alone_ms': {k: round(v, 4) for k, v in alone.items()},
+            'fit': {'residues': V, 'selected_orders': {str(listDoG[j]): int((best == j).sum()) for j in range(len(listDoG))},
+                    'unfitted': int((best < 0).sum()), 'evaluations_per_batch': nfev_step},
             'setup': {'synth_s': gen_s},
             **({'INVALID': 'fits skipped (--dev-skip-fits)'} if args.dev_skip_fits else {}),
         }
         if world == 1 and not args.no_cpu_baseline:
-            nvs = min(args.cpu_sample_vectors, V)
-            res['cpu_baseline'] = cpu_baseline(vecs_host[:, :nvs], s)
+            res['cpu_baseline'] = cpu_baseline(vecs_host, s, cfg, min(args.cpu_sample_vectors, V), min(args.cpu_allcore_vectors, V))
         else:
             res['cpu_baseline'] = None
         print(json.dumps(res))
     # deterministic teardown while the HIP runtime is alive: streams, pinned mirrors and the context's work areas go
     # here, not in __del__ / static destructors at interpreter exit
-    pipe.close()
     del vecs
     ctx.close()
     if world > 1:

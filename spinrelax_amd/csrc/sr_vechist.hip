@@ -10,10 +10,17 @@
 //   mean vector                 calculate-Ct-from-traj.py:579-583
 //   S2 outer products           calculate-Ct-from-traj.py:96-145
 //
-// Binning cost: float64 atan2 / acos / cos for every sample made the kernel FP64-issue bound (0.75 ms for cfg3,
-// 10 % of the HBM roofline).  A float32 estimate now classifies every sample that is clearly inside a bin; only
-// samples within a guard band of a bin edge (and NaNs) take the float64 path, so the counts stay bit-identical
-// to numpy's (tests/test_gpu_parity.py::test_vechist_*).
+// The kernel is HBM-bound by algorithm (one pass over 12 B per sample); what it must NOT do is spend float64 issue slots
+// per sample.  Round 1 rotated every sample in float64, ran nine float64 sums on the rotated values and decided the bin
+// from them (0.25 ms for cfg3 = 30 % of HBM).  Now:
+//   * sums: the rotation is linear, so sum R v = R sum v and sum (R v)(R v)^T = R (sum v v^T) R^T.  The kernel
+//     accumulates the UNROTATED float32 samples in float64 (products of two float32 are exact in float64) and
+//     k_vechist_finalize rotates the 3 + 6 sums once per (vector, block): 12 float64 instructions per sample instead of ~60;
+//   * bins: a float32 rotation + float32 (phi, cos theta) estimate classifies every sample that is clearly inside a
+//     bin; samples within a guard band of a bin edge, near the poles (where the float32 rotation error is amplified
+//     in phi), NaNs and out-of-range values take the exact path -- float64 rotation in the reference's operation
+//     order, atan2 / acos / cos, numpy's searchsorted rule -- so the counts stay bit-identical to numpy's
+//     (tests/test_gpu_parity.py::test_vechist_*).
 //
 // Work decomposition: grid = (frame ranges, vectors).  A workgroup owns one vector and a frame range
 // that lies inside one S2 block; its histogram lives in LDS as 32-bit counters (nphi*ncos*4 B = 10 KB
@@ -37,6 +44,7 @@ struct VhArgs {
     int nphi, ncos;
     int rotate;
     double qw, qx, qy, qz;
+    float fw, fx, fy, fz;     // the same unit quaternion in float32 (bin estimate only)
     const double *edges; // device: nphi+1 then ncos+1; null = the edges travel in edges_inline (no upload per call)
     double edges_inline[kInlineEdges];
     unsigned int *hist_u32;   // (nV, nphi*ncos)
@@ -84,38 +92,49 @@ __device__ __noinline__ void exact_phi_cos(double x, double y, double z, double 
     c = cos(acos(z / r));
 }
 
-// One sample: rotate (float64, reference operation order), accumulate the sums, histogram it.
-// Binning: a float32 estimate of (phi, cos theta) decides the bin when it lies at least kEdgeGuard bin widths
-// away from both edges of that bin -- the estimate is good to < 1e-6 rad / 5e-7, the guard band is 1.7e-5 rad /
-// 1.1e-5, so the decision is the one numpy's searchsorted makes on the float64 values; otherwise (4e-4 of the
-// samples, and every NaN / out-of-range value) the float64 atan2 / acos / cos path decides exactly like before.
+// One sample.  Sums: the unrotated float32 components in float64 (rotated once in k_vechist_finalize).
+// Binning: a float32 rotation and a float32 estimate of (phi, cos theta) decide the bin when the estimate lies at least
+// kEdgeGuard bin widths away from both edges of that bin and the vector is not within ~2 degrees of a pole.  Error
+// budget of the estimate: the float32 rotation is good to ~2.4e-7 absolute per component of a unit vector, i.e. 5.4e-6 rad
+// in phi once x^2 + y^2 > 4e-3 r^2 (farther than 3.6 degrees from a pole), and 6e-7 in cos theta; atan2f, rsqrtf and the
+// float32 scaling add < 1.5e-6 rad / 3e-7.  The guard band is the larger of 2e-4 bin widths and 1.7e-5 rad / 1.1e-5 (the
+// two coincide for the default 72 x 36 grid), so the decision is the one numpy's searchsorted makes on the float64
+// values; every other sample (~3e-3 of them, and every NaN / out-of-range value) takes the exact float64 path.
 constexpr float kEdgeGuard = 2e-4f;
+constexpr float kPhiGuardRad = 1.7e-5f, kCosGuard = 1.1e-5f;
 
 __device__ __forceinline__ void vh_sample(const VhArgs &a, float xf, float yf, float zf, bool in_block,
                                           const double *ephi, const double *ecos, unsigned int *h, VhAcc &s,
                                           float phi_scale, float cos_scale)
 {
-    double x = (double)xf, y = (double)yf, z = (double)zf;
-    if (a.rotate) {
-        double rx, ry, rz;
-        rotate_q(a.qw, a.qx, a.qy, a.qz, x, y, z, rx, ry, rz);
-        x = rx; y = ry; z = rz;
-    }
+    const double x = (double)xf, y = (double)yf, z = (double)zf;
     s.sx += x; s.sy += y; s.sz += z;
     if (in_block) {
-        s.oxx += x * x; s.oyy += y * y; s.ozz += z * z;
-        s.oxy += x * y; s.oxz += x * z; s.oyz += y * z;
+        s.oxx = fma(x, x, s.oxx); s.oyy = fma(y, y, s.oyy); s.ozz = fma(z, z, s.ozz);
+        s.oxy = fma(x, y, s.oxy); s.oxz = fma(x, z, s.oxz); s.oyz = fma(y, z, s.oyz);
     }
-    const float fx = (float)x, fy = (float)y, fz = (float)z;
+    float fx = xf, fy = yf, fz = zf;
+    if (a.rotate) {
+        const float ax = (a.fy * zf - a.fz * yf) + a.fw * xf;
+        const float ay = (a.fz * xf - a.fx * zf) + a.fw * yf;
+        const float az = (a.fx * yf - a.fy * xf) + a.fw * zf;
+        fx = xf + 2.0f * (a.fy * az - a.fz * ay);
+        fy = yf + 2.0f * (a.fz * ax - a.fx * az);
+        fz = zf + 2.0f * (a.fx * ay - a.fy * ax);
+    }
+    const float rxy2 = fx * fx + fy * fy, r2 = rxy2 + fz * fz;
     const float tp = (atan2f(fy, fx) + 3.14159265358979f) * phi_scale;          // position in phi-bin units
-    const float tc = (fz * rsqrtf((fx * fx + fy * fy) + fz * fz) + 1.0f) * cos_scale;
+    const float tc = (fz * rsqrtf(r2) + 1.0f) * cos_scale;
     const float kpf = floorf(tp), kcf = floorf(tc);
     int kp = (int)kpf, kc = (int)kcf;
-    const bool sure = (tp - kpf > kEdgeGuard) && (tp - kpf < 1.0f - kEdgeGuard) && (tc - kcf > kEdgeGuard) &&
-                      (tc - kcf < 1.0f - kEdgeGuard) && kp >= 0 && kp < a.nphi && kc >= 0 && kc < a.ncos;
+    const float gp = fmaxf(kEdgeGuard, kPhiGuardRad * phi_scale), gc = fmaxf(kEdgeGuard, kCosGuard * cos_scale);
+    const bool sure = (tp - kpf > gp) && (tp - kpf < 1.0f - gp) && (tc - kcf > gc) && (tc - kcf < 1.0f - gc) &&
+                      kp >= 0 && kp < a.nphi && kc >= 0 && kc < a.ncos &&
+                      (rxy2 > 4e-3f * r2) && (r2 > 1e-12f) && (r2 < 1e12f);
     if (!sure) {
-        double phi, c;
-        exact_phi_cos(x, y, z, phi, c);
+        double rx = x, ry = y, rz = z, phi, c;
+        if (a.rotate) rotate_q(a.qw, a.qx, a.qy, a.qz, x, y, z, rx, ry, rz);
+        exact_phi_cos(rx, ry, rz, phi, c);
         kp = np_bin(ephi, a.nphi, phi);
         kc = np_bin(ecos, a.ncos, c);
     }
@@ -198,26 +217,41 @@ __global__ __launch_bounds__(256) void k_vechist(VhArgs a)
     }
 }
 
+// histogram counters -> float64; per-range sums combined in fixed order, then rotated: sum R v = R sum v and
+// sum (R v)(R v)^T = R (sum v v^T) R^T with R the rotation matrix of the unit quaternion (identity without rotation)
+struct VhRot {
+    double R[3][3];
+};
+
 __global__ __launch_bounds__(256) void k_vechist_finalize(const unsigned int *__restrict__ hist_u32,
                                                           const double *__restrict__ partials, int64_t nV, int nbins,
-                                                          int nranges, int nB, int m, double *__restrict__ hist,
+                                                          int nranges, int nB, int m, VhRot rot, double *__restrict__ hist,
                                                           double *__restrict__ vecsum, double *__restrict__ outer)
 {
+#pragma clang fp contract(off)
     const int64_t v = blockIdx.x;
     const int tid = threadIdx.x;
     for (int i = tid; i < nbins; i += 256) hist[v * nbins + i] = (double)hist_u32[v * nbins + i];
     const double *p = partials + v * nranges * 9;
-    if (vecsum && tid < 3) {
-        double s = 0.0;
-        for (int r = 0; r < nranges; ++r) s += p[r * 9 + tid];
-        vecsum[v * 3 + tid] = s;
+    if (vecsum && tid == 0) {
+        double s[3] = {0.0, 0.0, 0.0};
+        for (int r = 0; r < nranges; ++r)
+            for (int k = 0; k < 3; ++k) s[k] += p[r * 9 + k];
+        for (int i = 0; i < 3; ++i) vecsum[v * 3 + i] = (rot.R[i][0] * s[0] + rot.R[i][1] * s[1]) + rot.R[i][2] * s[2];
     }
     if (outer) {
-        for (int i = tid; i < nB * 6; i += 256) {
-            const int b = i / 6, k = i - b * 6;
-            double s = 0.0;
-            for (int j = 0; j < m; ++j) s += p[(b * m + j) * 9 + 3 + k];
-            outer[((int64_t)b * nV + v) * 6 + k] = s;
+        for (int b = tid; b < nB; b += 256) {
+            double q[6] = {0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < m; ++j)
+                for (int k = 0; k < 6; ++k) q[k] += p[(b * m + j) * 9 + 3 + k];
+            const double M[3][3] = {{q[0], q[3], q[4]}, {q[3], q[1], q[5]}, {q[4], q[5], q[2]}};
+            double T[3][3], O[3][3];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) T[i][j] = (rot.R[i][0] * M[0][j] + rot.R[i][1] * M[1][j]) + rot.R[i][2] * M[2][j];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) O[i][j] = (T[i][0] * rot.R[j][0] + T[i][1] * rot.R[j][1]) + T[i][2] * rot.R[j][2];
+            double *o = outer + ((int64_t)b * nV + v) * 6;
+            o[0] = O[0][0]; o[1] = O[1][1]; o[2] = O[2][2]; o[3] = O[0][1]; o[4] = O[0][2]; o[5] = O[1][2];
         }
     }
 }
@@ -297,6 +331,16 @@ int sr_rotate_hist_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t 
         normalise_q(q_host, qn);
         a.qw = qn[0]; a.qx = qn[1]; a.qy = qn[2]; a.qz = qn[3];
     }
+    a.fw = (float)a.qw; a.fx = (float)a.qx; a.fy = (float)a.qy; a.fz = (float)a.qz;
+    VhRot rot;
+    {
+        const double w = a.qw, x = a.qx, y = a.qy, z = a.qz;
+        const double Rm[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
+                                 {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
+                                 {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) rot.R[i][j] = a.rotate ? Rm[i][j] : (i == j ? 1.0 : 0.0);
+    }
     const int ne = nphi + 1 + ncos + 1;
     const size_t misc_bytes = (size_t)ne * sizeof(double);
     double *edges_d = nullptr;
@@ -322,7 +366,7 @@ int sr_rotate_hist_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t 
     hipLaunchKernelGGL(k_vechist, dim3((unsigned)a.nranges, (unsigned)nV), dim3(256), lds, ctx->stream, a);
     SR_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_vechist_finalize, dim3((unsigned)nV), dim3(256), 0, ctx->stream, h32, partials, nV, nbins,
-                       a.nranges, a.nB, a.m, hist, vecsum, outer);
+                       a.nranges, a.nB, a.m, rot, hist, vecsum, outer);
     SR_HIP(hipGetLastError());
     return 0;
 }

@@ -325,8 +325,8 @@ class DevicePipeline:
         """Throughput half of batch k.  Serial form (depth 1): pack, C(t), histogram, transposes on the main stream.
         Overlapped form: C(t) + transposes on the main stream; the histogram of batch k and the pack of batch k+1
         (`pack_next`: its vectors) on the auxiliary stream, beside the C(t) launch, on alternating plane buffers.
-        events: [before the C(t) kernel, after it (before its finalize), before histogram, after histogram]; the first
-        two on the main stream."""
+        events: [before the C(t) kernel, after it (before its finalize), before histogram, after histogram, (4, 5: see
+        back())]; the first two on the main stream."""
         s = self.slots[k % self.depth]
         if self.aux is None:
             self.ctx.set_stream(self.main.cuda_stream)
@@ -397,8 +397,9 @@ class DevicePipeline:
         self.ctx.set_stream(self.main.cuda_stream)
         return s
 
-    def back(self, k):
-        """Latency half of batch k on the slot's own stream: model-order search, relaxation, copies to pinned memory."""
+    def back(self, k, events=None):
+        """Latency half of batch k on the slot's own stream: model-order search, relaxation, copies to pinned memory.
+        events (optional): [4] and [5] are recorded around the search kernel on the slot's stream."""
         s = self.slots[k % self.depth]
         if s.stream is not self.main:
             s.stream.wait_event(s.front_done)
@@ -408,7 +409,11 @@ class DevicePipeline:
             if self.aux is not None and self.tail_on_slot_stream:
                 self.stage_ct_finalize(s)
                 self.stage_transpose(s)
+            if events is not None and len(events) > 5:
+                events[4].record(s.stream)
             self.stage_fit(s)
+            if events is not None and len(events) > 5:
+                events[5].record(s.stream)
             self.stage_relax(s)
             self.stage_download(s)
             s.done = torch.cuda.Event()
@@ -441,7 +446,7 @@ class DevicePipeline:
                 if on_finished is not None:
                     on_finished(s)
             self.front(vecs, k, None if events is None else events[k], pack_next=vecs if k + 1 < nb else None)
-            self.back(k)
+            self.back(k, None if events is None else events[k])
         for k in range(max(0, nb - D), nb):
             s = self.slots[k % D]
             if s.busy:

@@ -5,6 +5,10 @@ files (<o>_Ctext.dat, <o>_Ctint.dat, <o>_vecHistogram.npz | _vecPhiTheta.npz|.da
 <o>_S2.dat).  C(t), the rotation into the PAF, the spherical histogram, the mean vector and S2 are
 computed on the MI355X (libspinrelax_hip.so); this script only parses arguments and moves files.
 
+Several GPUs: run under torchrun (`torchrun --nproc-per-node N scripts/calculate-Ct-from-traj.py ...`): rank r computes the
+contiguous vector range spinrelax_amd.dist.shard_range gives it, the results are all-gathered (RCCL) and rank 0 writes the
+same files a single process writes.
+
 Trajectory input:
   * with MDTraj installed: -s <pdb> -f <xtc ...> exactly like the reference; MDTraj only reads the files and
     resolves the atom selections, the bond vectors, the centring and the per-frame superposition (reference lines
@@ -24,6 +28,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spinrelax_amd import ct as hostct                      # noqa: E402
+from spinrelax_amd import dist as srdist                    # noqa: E402
 from spinrelax_amd import general_scripts as gs             # noqa: E402
 
 
@@ -146,6 +151,7 @@ def load_mdtraj(args):
 def main():
     args = build_parser().parse_args()
     time_start = time.time()
+    rank, world = srdist.start()
     if args.help_sel:
         print("Notes: This program uses MDTraj selection syntax, e.g. 'chain A and resname GLY and name HA1 HA2'.")
         sys.exit(0)
@@ -185,7 +191,7 @@ def main():
         print("= = = ERROR: delta-t form the trajectory is too small relative to tau! %g vs. %g" % (deltaT, tau_memory), file=sys.stderr)
         sys.exit(1)
     print("= = Loading finished.")
-    out_pref = args.out_pref
+    out_pref = srdist.output_prefix(args.out_pref)
 
     if tau_memory is not None:
         F = int(tau_memory / deltaT)
@@ -251,6 +257,7 @@ def main():
         gs.print_xylist(out_pref + '_S2.dat', resXH, (S2.T) * args.zeta, True)
         print("      ...complete.")
     print("= = Finished. Total seconds elapsed: %g" % (time.time() - time_start))
+    srdist.finish()
 
 
 if __name__ == '__main__':

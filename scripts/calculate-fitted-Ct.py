@@ -15,6 +15,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spinrelax_amd import general_scripts as gs             # noqa: E402
 from spinrelax_amd import fitting_Ct_functions as fitCt     # noqa: E402
+from spinrelax_amd import dist as srdist                    # noqa: E402
 
 
 def main():
@@ -27,6 +28,7 @@ def main():
     p.add_argument('--nofast', dest='bNoFast', action='store_true', default=False, help='Forbid the S_fast component (C(0) must be one).')
     args = p.parse_args()
     time_start = time.time()
+    srdist.start()          # under torchrun: residues are split over the ranks inside fit_all, rank 0 writes the file
 
     files = args.in_Ct_fn
     print("= = = Found %d input C(t) files." % len(files))
@@ -60,10 +62,11 @@ def main():
     listDoGs = [2, 3, 5, 7, 9] if bUseSFast else [2, 4, 6, 8]
     print("...Running C(t)-fits for %d residues on the GPU (orders %s)." % (len(legs), str(listDoGs if args.nc == -1 else args.nc)))
     autoCorrs.fit_all(listDoG=listDoGs, chiSqThreshold=0.5, nc=args.nc, bUseSFast=bUseSFast)
-    out_fn = args.out_pref + '_fittedCt.dat'
+    out_fn = srdist.output_prefix(args.out_pref) + '_fittedCt.dat'
     autoCorrs.export(fileName=out_fn, style='xmgrace')
     print(" = = Completed C(t)-fits.")
     print("= = Finished. Total seconds elapsed: %g" % (time.time() - time_start))
+    srdist.finish()
 
 
 if __name__ == '__main__':

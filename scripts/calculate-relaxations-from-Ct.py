@@ -22,6 +22,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spinrelax_amd import general_scripts as gs             # noqa: E402
 from spinrelax_amd import fitting_Ct_functions as fitCt     # noqa: E402
 from spinrelax_amd import spectral_densities as sd          # noqa: E402
+from spinrelax_amd import dist as srdist                    # noqa: E402
 
 
 def sanity_check_two_list(listA, listB, string):
@@ -78,7 +79,8 @@ def build_parser():
 def main():
     time_start = time.time()
     args = build_parser().parse_args()
-    out_pref = args.out_pref
+    srdist.start()          # under torchrun: residues are split over the ranks inside every batched evaluation, rank 0 writes
+    out_pref = srdist.output_prefix(args.out_pref)
     if args.opt is not None:
         if args.expfn is None:
             print("= = = ERROR: Cannot conduct optimisation without a target experimental scattering file! (Missing --expfn )", file=sys.stderr)
@@ -265,6 +267,7 @@ def main():
         gs.print_xydy(out_pref + '_NOE.dat', sim_resid, datablock[2, :, 0], datablock[2, :, 1], header=optHeader)
         gs.print_xydy(out_pref + '_rho.dat', sim_resid, datablock[3, :, 0], datablock[3, :, 1])
     print("= = Finished. Total seconds elapsed: %g" % (time.time() - time_start))
+    srdist.finish()
 
 
 if __name__ == '__main__':

@@ -19,6 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spinrelax_amd import general_scripts as gs             # noqa: E402
 from spinrelax_amd import fitting_Ct_functions as fitCt     # noqa: E402
 from spinrelax_amd import spectral_densities as sd          # noqa: E402
+from spinrelax_amd import dist as srdist                    # noqa: E402
 
 
 def parse_rotdif_params(D=None, tau=None, aniso=None):
@@ -61,6 +62,8 @@ def main():
     p.add_argument('--tol', type=float, default=1e-6, help='Fractional-change tolerance of the global/local cycles.')
     args = p.parse_args()
     time_start = time.time()
+    srdist.start()          # under torchrun: every batched evaluation splits the residues over the ranks; rank 0 writes
+    args.out_pref = srdist.output_prefix(args.out_pref)
 
     localCtModel = fitCt.read_fittedCt_parameters(args.in_Ct_fn)
     if localCtModel.nModels == 0:
@@ -108,6 +111,7 @@ def main():
         objExpts.eval_all(bVerbose=True)
         objExpts.export_xvg(args.out_pref, bIncludeExpt=False)
         print("= = Finished. Total seconds elapsed: %g" % (time.time() - time_start))
+        srdist.finish()
         sys.exit()
 
     objExpts.parse_optimisation_params(args.listOptParams.split(','))
@@ -123,6 +127,7 @@ def main():
             for x, y in zip(objExpts.localCtModels.get_names(), objExpts.get_first_csa()):
                 print("%s %g" % (x, y), file=fp)
     print("= = Finished. Total seconds elapsed: %g (%d objective evaluations)" % (time.time() - time_start, objExpts.nObjectiveCalls))
+    srdist.finish()
 
 
 if __name__ == '__main__':

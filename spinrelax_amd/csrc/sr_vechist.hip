@@ -44,7 +44,7 @@ struct VhArgs {
     int nphi, ncos;
     int rotate;
     double qw, qx, qy, qz;
-    float fw, fx, fy, fz;     // the same unit quaternion in float32 (bin estimate only)
+    float rm[9];              // rotation matrix of the same quaternion in float32, row-major (bin estimate only)
     const double *edges; // device: nphi+1 then ncos+1; null = the edges travel in edges_inline (no upload per call)
     double edges_inline[kInlineEdges];
     unsigned int *hist_u32;   // (nV, nphi*ncos)
@@ -103,113 +103,228 @@ __device__ __noinline__ void exact_phi_cos(double x, double y, double z, double 
 constexpr float kEdgeGuard = 2e-4f;
 constexpr float kPhiGuardRad = 1.7e-5f, kCosGuard = 1.1e-5f;
 
-__device__ __forceinline__ void vh_sample(const VhArgs &a, float xf, float yf, float zf, bool in_block,
-                                          const double *ephi, const double *ecos, unsigned int *h, VhAcc &s,
-                                          float phi_scale, float cos_scale)
+constexpr int kMaxRange = 8192;      // frames per range: bounds the LDS mask (1 KB) and list (16 KB) of undecided samples
+
+// exact (reference-order, float64) classification of one sample
+__device__ __forceinline__ void vh_exact(const VhArgs &a, float xf, float yf, float zf, const double *ephi, const double *ecos,
+                                         unsigned int *h)
+{
+    const double x = (double)xf, y = (double)yf, z = (double)zf;
+    double rx = x, ry = y, rz = z, phi, c;
+    if (a.rotate) rotate_q(a.qw, a.qx, a.qy, a.qz, x, y, z, rx, ry, rz);
+    exact_phi_cos(rx, ry, rz, phi, c);
+    const int kp = np_bin(ephi, a.nphi, phi), kc = np_bin(ecos, a.ncos, c);
+    if (kp >= 0 && kc >= 0) atomicAdd(&h[kp * a.ncos + kc], 1u);
+}
+
+// atan2(y, x) in float32 without libm: octant reduction, one v_rcp_f32, a degree-7 polynomial in (min/max)^2 fitted to
+// atan(a)/a on [0, 1] (max error 1.5e-7 rad in float32 Horner form), quadrant fix-ups.  Good to < 6e-7 rad; signed
+// zeros and x = y = 0 do not matter here (such samples sit on a bin edge or are NaN and take the exact path anyway).
+__device__ __forceinline__ float fast_atan2f(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const float u = t * t;
+    float p = -0.00455979211f;
+    p = fmaf(p, u, 0.0237805191f);
+    p = fmaf(p, u, -0.0588297546f);
+    p = fmaf(p, u, 0.0986886546f);
+    p = fmaf(p, u, -0.140032902f);
+    p = fmaf(p, u, 0.199669614f);
+    p = fmaf(p, u, -0.333318114f);
+    p = fmaf(p, u, 0.999999881f);
+    float r = t * p;
+    r = ay > ax ? 1.57079632679f - r : r;
+    r = x < 0.f ? 3.14159265359f - r : r;
+    return y < 0.f ? -r : r;
+}
+
+// One sample, branch-free.  Sums: the unrotated float32 components in float64 (rotated once in k_vechist_finalize).
+// Bin: decided from the float32 estimate when it is safe (see above); ONE LDS atomic either way -- a decided sample adds 1
+// to its bin, an undecided one sets its bit (idx = its position in the range) in the LDS mask; the marked samples are
+// collected and classified exactly, one per thread, when the range has been streamed.  (Taken inline, the ~600-instruction
+// float64 path of one lane in ~300 would stall the other 63 lanes of its wave in one of six iterations.)
+template <bool ROT, bool INB>
+__device__ __forceinline__ void vh_sample(const VhArgs &a, float xf, float yf, float zf, unsigned int idx, unsigned int *h,
+                                          unsigned int *mask, VhAcc &s, float phi_scale, float cos_scale, float hp, float hc)
 {
     const double x = (double)xf, y = (double)yf, z = (double)zf;
     s.sx += x; s.sy += y; s.sz += z;
-    if (in_block) {
+    if (INB) {
         s.oxx = fma(x, x, s.oxx); s.oyy = fma(y, y, s.oyy); s.ozz = fma(z, z, s.ozz);
         s.oxy = fma(x, y, s.oxy); s.oxz = fma(x, z, s.oxz); s.oyz = fma(y, z, s.oyz);
     }
     float fx = xf, fy = yf, fz = zf;
-    if (a.rotate) {
-        const float ax = (a.fy * zf - a.fz * yf) + a.fw * xf;
-        const float ay = (a.fz * xf - a.fx * zf) + a.fw * yf;
-        const float az = (a.fx * yf - a.fy * xf) + a.fw * zf;
-        fx = xf + 2.0f * (a.fy * az - a.fz * ay);
-        fy = yf + 2.0f * (a.fz * ax - a.fx * az);
-        fz = zf + 2.0f * (a.fx * ay - a.fy * ax);
+    if (ROT) {                                     // float32 rotation matrix of the unit quaternion (estimate only)
+        fx = fmaf(a.rm[0], xf, fmaf(a.rm[1], yf, a.rm[2] * zf));
+        fy = fmaf(a.rm[3], xf, fmaf(a.rm[4], yf, a.rm[5] * zf));
+        fz = fmaf(a.rm[6], xf, fmaf(a.rm[7], yf, a.rm[8] * zf));
     }
-    const float rxy2 = fx * fx + fy * fy, r2 = rxy2 + fz * fz;
-    const float tp = (atan2f(fy, fx) + 3.14159265358979f) * phi_scale;          // position in phi-bin units
-    const float tc = (fz * rsqrtf(r2) + 1.0f) * cos_scale;
+    const float rxy2 = fmaf(fx, fx, fy * fy), r2 = fmaf(fz, fz, rxy2);
+    const float tp = (fast_atan2f(fy, fx) + 3.14159265358979f) * phi_scale;     // position in phi-bin units
+    const float tc = fmaf(fz, rsqrtf(r2), 1.0f) * cos_scale;
     const float kpf = floorf(tp), kcf = floorf(tc);
-    int kp = (int)kpf, kc = (int)kcf;
-    const float gp = fmaxf(kEdgeGuard, kPhiGuardRad * phi_scale), gc = fmaxf(kEdgeGuard, kCosGuard * cos_scale);
-    const bool sure = (tp - kpf > gp) && (tp - kpf < 1.0f - gp) && (tc - kcf > gc) && (tc - kcf < 1.0f - gc) &&
-                      kp >= 0 && kp < a.nphi && kc >= 0 && kc < a.ncos &&
-                      (rxy2 > 4e-3f * r2) && (r2 > 1e-12f) && (r2 < 1e12f);
-    if (!sure) {
-        double rx = x, ry = y, rz = z, phi, c;
-        if (a.rotate) rotate_q(a.qw, a.qx, a.qy, a.qz, x, y, z, rx, ry, rz);
-        exact_phi_cos(rx, ry, rz, phi, c);
-        kp = np_bin(ephi, a.nphi, phi);
-        kc = np_bin(ecos, a.ncos, c);
-    }
-    if (kp >= 0 && kc >= 0) atomicAdd(&h[kp * a.ncos + kc], 1u);
+    // inside the bin by more than the guard band on both sides:  |frac - 1/2| < 1/2 - guard   (hp, hc = 1/2 - guard).
+    // A position outside the grid (or NaN) fails this by itself: tp, tc only leave [0, n] by rounding, i.e. next to an edge.
+    const bool sure = (int)(fabsf((tp - kpf) - 0.5f) < hp) & (int)(fabsf((tc - kcf) - 0.5f) < hc) & (int)(rxy2 > 4e-3f * r2) &
+                      (int)(r2 > 1e-30f);
+    const int bin = (int)kpf * a.ncos + (int)kcf;
+    unsigned int *addr = sure ? h + bin : mask + (idx >> 5);
+    atomicAdd(addr, sure ? 1u : (1u << (idx & 31)));
 }
 
-__global__ __launch_bounds__(256) void k_vechist(VhArgs a)
+// The samples of one range, by ONE WAVE, through the fast classification (sums into s, decided samples into h, the others
+// marked in the wave's mask).  16-byte loads of 4 consecutive frames, software-pipelined: a lane owns groups lane + 64 k of
+// the range and always has the loads of the NEXT two groups (6 x 16 B) in flight while it classifies the current two.
+template <bool ROT, bool INB>
+__device__ __forceinline__ void vh_range(const VhArgs &a, const float *px, const float *py, const float *pz, int64_t start,
+                                         int64_t end, int lane, unsigned int *h, unsigned int *mask, VhAcc &s, float phi_scale,
+                                         float cos_scale, float hp, float hc)
+{
+    int64_t n0 = start;
+    if ((start & 3) == 0) {
+        const int64_t nvec = (end - start) >> 2;
+        float4 XA[2], YA[2], ZA[2], XB[2], YB[2], ZB[2];
+#define SR_VH_LOAD2(G, X, Y, Z)                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                          \
+            int64_t q = (G) + lane + 64 * j;                                                     \
+            q = q < nvec ? q : nvec - 1;                                                         \
+            const int64_t n = start + (q << 2);                                                  \
+            X[j] = *reinterpret_cast<const float4 *>(px + n);                                    \
+            Y[j] = *reinterpret_cast<const float4 *>(py + n);                                    \
+            Z[j] = *reinterpret_cast<const float4 *>(pz + n);                                    \
+        }
+#define SR_VH_COMP2(G, X, Y, Z)                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                          \
+            const int64_t q = (G) + lane + 64 * j;                                               \
+            if (q < nvec) {                                                                      \
+                const unsigned int i0 = (unsigned int)(q << 2);                                  \
+                vh_sample<ROT, INB>(a, X[j].x, Y[j].x, Z[j].x, i0 + 0, h, mask, s, phi_scale, cos_scale, hp, hc); \
+                vh_sample<ROT, INB>(a, X[j].y, Y[j].y, Z[j].y, i0 + 1, h, mask, s, phi_scale, cos_scale, hp, hc); \
+                vh_sample<ROT, INB>(a, X[j].z, Y[j].z, Z[j].z, i0 + 2, h, mask, s, phi_scale, cos_scale, hp, hc); \
+                vh_sample<ROT, INB>(a, X[j].w, Y[j].w, Z[j].w, i0 + 3, h, mask, s, phi_scale, cos_scale, hp, hc); \
+            }                                                                                    \
+        }
+        if (nvec > 0) {
+            SR_VH_LOAD2(0, XA, YA, ZA)
+            for (int64_t g0 = 0; g0 < nvec; g0 += 256) {
+                SR_VH_LOAD2(g0 + 128, XB, YB, ZB)
+                SR_VH_COMP2(g0, XA, YA, ZA)
+                SR_VH_LOAD2(g0 + 256, XA, YA, ZA)
+                SR_VH_COMP2(g0 + 128, XB, YB, ZB)
+            }
+        }
+#undef SR_VH_LOAD2
+#undef SR_VH_COMP2
+        n0 = start + (nvec << 2);
+    }
+    for (int64_t n = n0 + lane; n < end; n += 64)
+        vh_sample<ROT, INB>(a, px[n], py[n], pz[n], (unsigned int)(n - start), h, mask, s, phi_scale, cos_scale, hp, hc);
+}
+
+// grid = (groups of 4 ranges, vectors): a workgroup keeps one vector's histogram in LDS; each of its 4 waves streams one
+// range by itself (no barrier, no cross-wave reduction while streaming: a wave reduces its own nine sums with DPP and lane 0
+// stores them), then the workgroup classifies the parked samples of all four ranges together and flushes the histogram.
+constexpr int kRangesPerWG = 4;
+constexpr int kListCap = 4096;       // parked samples a workgroup classifies densely; beyond that (pathological input:
+                                     // every sample undecided) the collecting thread classifies them itself
+
+__global__ __launch_bounds__(256, 4) void k_vechist(VhArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double *edges = reinterpret_cast<double *>(smem);                 // nphi+1 + ncos+1
     const int ne = a.nphi + 1 + a.ncos + 1;
-    double *red = edges + ne;                                         // 4 waves x 9
-    unsigned int *h = reinterpret_cast<unsigned int *>(red + 36);     // nphi*ncos
+    unsigned int *h = reinterpret_cast<unsigned int *>(edges + ne);   // nphi*ncos
     const int nbins = a.nphi * a.ncos;
+    unsigned int *mask = h + ((nbins + 3) & ~3);                      // 4 x kMaxRange bits: undecided samples per wave / range
+    unsigned int *qcount = mask + kRangesPerWG * (kMaxRange / 32);    // their number (+ pad) ...
+    unsigned short *qlist = reinterpret_cast<unsigned short *>(qcount + 4);   // ... and (wave << 13 | position in the range)
     const int tid = threadIdx.x;
-    const int rid = blockIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int64_t v = blockIdx.y;
 
     for (int i = tid; i < ne; i += 256) edges[i] = a.edges ? a.edges[i] : a.edges_inline[i];
     for (int i = tid; i < nbins; i += 256) h[i] = 0u;
+    for (int i = tid; i < kRangesPerWG * (kMaxRange / 32); i += 256) mask[i] = 0u;
+    if (tid == 0) *qcount = 0u;
     __syncthreads();
     const double *ephi = edges, *ecos = edges + a.nphi + 1;
     // the float32 estimate assumes the uniform numpy.linspace edges of calculate-Ct-from-traj.py:618
     const float phi_scale = (float)((double)a.nphi / (ephi[a.nphi] - ephi[0]));
     const float cos_scale = (float)((double)a.ncos / (ecos[a.ncos] - ecos[0]));
-
-    int64_t start, end;
-    bool in_block;
-    if (rid < a.nB * a.m) {
-        const int b = rid / a.m, i = rid - b * a.m;
-        start = (int64_t)b * a.Fb + (int64_t)i * a.sub;
-        end = min(start + a.sub, (int64_t)(b + 1) * a.Fb);
-        in_block = true;
-    } else {
-        start = (int64_t)a.nB * a.Fb;
-        end = a.N;
-        in_block = false;
-    }
+    const float hp = 0.5f - fmaxf(kEdgeGuard, kPhiGuardRad * phi_scale), hc = 0.5f - fmaxf(kEdgeGuard, kCosGuard * cos_scale);
     const float *px = a.soa + (v * 3) * a.Npad;
     const float *py = px + a.Npad;
     const float *pz = py + a.Npad;
 
-    VhAcc s = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t n0 = start;
-    if ((start & 3) == 0) {
-        // 16-byte loads: 4 consecutive frames per thread
-        const int64_t nvec = (end - start) >> 2;
-        for (int64_t q = tid; q < nvec; q += 256) {
-            const int64_t n = start + (q << 2);
-            const float4 X = *reinterpret_cast<const float4 *>(px + n);
-            const float4 Y = *reinterpret_cast<const float4 *>(py + n);
-            const float4 Z = *reinterpret_cast<const float4 *>(pz + n);
-            vh_sample(a, X.x, Y.x, Z.x, in_block, ephi, ecos, h, s, phi_scale, cos_scale);
-            vh_sample(a, X.y, Y.y, Z.y, in_block, ephi, ecos, h, s, phi_scale, cos_scale);
-            vh_sample(a, X.z, Y.z, Z.z, in_block, ephi, ecos, h, s, phi_scale, cos_scale);
-            vh_sample(a, X.w, Y.w, Z.w, in_block, ephi, ecos, h, s, phi_scale, cos_scale);
+    const int rid = blockIdx.x * kRangesPerWG + wave;                 // this wave's range
+    int64_t start = 0, end = 0;
+    if (rid < a.nranges) {
+        bool in_block;
+        if (rid < a.nB * a.m) {
+            const int b = rid / a.m, i = rid - b * a.m;
+            start = (int64_t)b * a.Fb + (int64_t)i * a.sub;
+            end = min(start + a.sub, (int64_t)(b + 1) * a.Fb);
+            in_block = true;
+        } else {                                                      // frames behind the last full S2 block
+            start = (int64_t)a.nB * a.Fb + (int64_t)(rid - a.nB * a.m) * a.sub;
+            end = min(start + a.sub, a.N);
+            in_block = false;
         }
-        n0 = start + (nvec << 2);
-    }
-    for (int64_t n = n0 + tid; n < end; n += 256)
-        vh_sample(a, px[n], py[n], pz[n], in_block, ephi, ecos, h, s, phi_scale, cos_scale);
-
-    // block reduction of the 9 sums (fixed order: lanes by DPP butterfly, then waves 0..3)
-    double vals[9] = {s.sx, s.sy, s.sz, s.oxx, s.oyy, s.ozz, s.oxy, s.oxz, s.oyz};
-    const int lane = tid & 63, wave = tid >> 6;
+        unsigned int *wmask = mask + wave * (kMaxRange / 32);
+        VhAcc s = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (a.rotate) {
+            if (in_block) vh_range<true, true>(a, px, py, pz, start, end, lane, h, wmask, s, phi_scale, cos_scale, hp, hc);
+            else vh_range<true, false>(a, px, py, pz, start, end, lane, h, wmask, s, phi_scale, cos_scale, hp, hc);
+        } else {
+            if (in_block) vh_range<false, true>(a, px, py, pz, start, end, lane, h, wmask, s, phi_scale, cos_scale, hp, hc);
+            else vh_range<false, false>(a, px, py, pz, start, end, lane, h, wmask, s, phi_scale, cos_scale, hp, hc);
+        }
+        // the wave's nine sums (fixed order: DPP butterfly), stored by lane 0..8
+        double vals[9] = {s.sx, s.sy, s.sz, s.oxx, s.oyy, s.ozz, s.oxy, s.oxz, s.oyz};
+        double mine = 0.0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const double t = sr_wave_sum_f64(vals[k]);
-        if (lane == 0) red[wave * 9 + k] = t;
+        for (int k = 0; k < 9; ++k) {
+            const double t = sr_wave_sum_f64(vals[k]);
+            if (lane == k) mine = t;
+        }
+        if (lane < 9) a.partials[(v * a.nranges + rid) * 9 + lane] = mine;
+    }
+    __syncthreads();                                                  // every sample of the four ranges is counted or marked
+    // collect the undecided samples (four mask words per thread), then classify them densely, one per thread
+    for (int w = tid; w < kRangesPerWG * (kMaxRange / 32); w += 256) {
+        unsigned int bits = mask[w];
+        const int wv = w / (kMaxRange / 32), w0 = w - wv * (kMaxRange / 32);
+        while (bits) {
+            const int bpos = __ffs((int)bits) - 1;
+            bits &= bits - 1u;
+            const unsigned int slot = atomicAdd(qcount, 1u);
+            const unsigned int pos = (unsigned int)(w0 * 32 + bpos);
+            if (slot < (unsigned int)kListCap) {
+                qlist[slot] = (unsigned short)((wv << 13) | pos);
+            } else {
+                const int r2 = blockIdx.x * kRangesPerWG + wv;
+                const int64_t st2 = r2 < a.nB * a.m ? (int64_t)(r2 / a.m) * a.Fb + (int64_t)(r2 % a.m) * a.sub
+                                                     : (int64_t)a.nB * a.Fb + (int64_t)(r2 - a.nB * a.m) * a.sub;
+                vh_exact(a, px[st2 + pos], py[st2 + pos], pz[st2 + pos], ephi, ecos, h);
+            }
+        }
     }
     __syncthreads();
-    if (tid < 9) {
-        const double t = ((red[tid] + red[9 + tid]) + red[18 + tid]) + red[27 + tid];
-        a.partials[(v * a.nranges + rid) * 9 + tid] = t;
+    {
+        const unsigned int nq = min(*qcount, (unsigned int)kListCap);
+        for (unsigned int i = tid; i < nq; i += 256) {
+            const unsigned int e = qlist[i];
+            const int wv = (int)(e >> 13);
+            const int r2 = blockIdx.x * kRangesPerWG + wv;
+            const int64_t st2 = r2 < a.nB * a.m ? (int64_t)(r2 / a.m) * a.Fb + (int64_t)(r2 % a.m) * a.sub
+                                                 : (int64_t)a.nB * a.Fb + (int64_t)(r2 - a.nB * a.m) * a.sub;
+            const int64_t n = st2 + (e & 8191u);
+            vh_exact(a, px[n], py[n], pz[n], ephi, ecos, h);
+        }
     }
+    __syncthreads();
     unsigned int *gh = a.hist_u32 + v * nbins;
     for (int i = tid; i < nbins; i += 256) {
         const unsigned int c = h[i];
@@ -312,17 +427,21 @@ int sr_rotate_hist_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t 
     a.soa = soa; a.Npad = Npad; a.N = N;
     a.Fb = (block_len > 0 && block_len <= N) ? block_len : N;
     a.nB = (int)(N / a.Fb);
-    // enough workgroups to fill the chip: aim at >= 4096 in total, each at least 1024 frames
-    int64_t want = (4096 + nV - 1) / nV;
+    // ranges: every S2 block is cut into m ranges of `sub` frames (a multiple of 4, at most kMaxRange: the LDS mask and
+    // list of undecided samples are sized for it); enough of them that the grid fills the chip (>= ~1024 workgroups of
+    // kRangesPerWG ranges each), each at least 1024 frames; the frames behind the last full block form further ranges
+    int64_t want = (1024 * kRangesPerWG + nV - 1) / nV;
     int64_t per_block = (want + a.nB - 1) / a.nB;
     if (per_block < 1) per_block = 1;
-    int64_t maxm = (a.Fb + 1023) / 1024;
+    const int64_t maxm = (a.Fb + 1023) / 1024, minm = (a.Fb + kMaxRange - 1) / kMaxRange;
     if (per_block > maxm) per_block = maxm;
+    if (per_block < minm) per_block = minm;
     a.m = (int)per_block;
     a.sub = sr_round_up((a.Fb + a.m - 1) / a.m, 4);
+    if (a.sub > kMaxRange) a.sub = kMaxRange;
     a.m = (int)((a.Fb + a.sub - 1) / a.sub);
-    const bool tail = (int64_t)a.nB * a.Fb < N;
-    a.nranges = a.nB * a.m + (tail ? 1 : 0);
+    const int64_t tail = N - (int64_t)a.nB * a.Fb;
+    a.nranges = a.nB * a.m + (int)((tail + a.sub - 1) / a.sub);
     a.nphi = nphi; a.ncos = ncos;
     a.rotate = q_host ? 1 : 0;
     a.qw = 1; a.qx = a.qy = a.qz = 0;
@@ -331,7 +450,6 @@ int sr_rotate_hist_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t 
         normalise_q(q_host, qn);
         a.qw = qn[0]; a.qx = qn[1]; a.qy = qn[2]; a.qz = qn[3];
     }
-    a.fw = (float)a.qw; a.fx = (float)a.qx; a.fy = (float)a.qy; a.fz = (float)a.qz;
     VhRot rot;
     {
         const double w = a.qw, x = a.qx, y = a.qy, z = a.qz;
@@ -339,7 +457,10 @@ int sr_rotate_hist_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t 
                                  {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
                                  {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
         for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) rot.R[i][j] = a.rotate ? Rm[i][j] : (i == j ? 1.0 : 0.0);
+            for (int j = 0; j < 3; ++j) {
+                rot.R[i][j] = a.rotate ? Rm[i][j] : (i == j ? 1.0 : 0.0);
+                a.rm[i * 3 + j] = (float)rot.R[i][j];
+            }
     }
     const int ne = nphi + 1 + ncos + 1;
     const size_t misc_bytes = (size_t)ne * sizeof(double);
@@ -361,9 +482,10 @@ int sr_rotate_hist_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t 
     }
     SR_HIP(hipMemsetAsync(h32, 0, (size_t)nV * nbins * sizeof(unsigned int), ctx->stream));
     a.edges = edges_d; a.hist_u32 = h32; a.partials = partials;
-    const size_t lds = (size_t)ne * sizeof(double) + 36 * sizeof(double) + (size_t)nbins * sizeof(unsigned int);
+    const size_t lds = (size_t)ne * sizeof(double) + (size_t)((nbins + 3) & ~3) * sizeof(unsigned int) +
+                       (kRangesPerWG * (kMaxRange / 32) + 4) * sizeof(unsigned int) + (size_t)kListCap * sizeof(unsigned short);
     if (int rc = sr_grant_lds(ctx, SR_K_VECHIST, reinterpret_cast<const void *>(&k_vechist), lds)) return rc;
-    hipLaunchKernelGGL(k_vechist, dim3((unsigned)a.nranges, (unsigned)nV), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL(k_vechist, dim3((unsigned)((a.nranges + kRangesPerWG - 1) / kRangesPerWG), (unsigned)nV), dim3(256), lds, ctx->stream, a);
     SR_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_vechist_finalize, dim3((unsigned)nV), dim3(256), 0, ctx->stream, h32, partials, nV, nbins,
                        a.nranges, a.nB, a.m, rot, hist, vecsum, outer);

@@ -9,6 +9,7 @@ import sys
 import numpy as np
 
 from . import hip
+from . import dist as srdist
 
 
 def _ctx(ctx):
@@ -79,6 +80,17 @@ def calculate_Ct_from_files(vec_list, dt, tau, ctx=None, mode=0, v0=0, nV=None):
     if R < 1:
         print("= = = ERROR: no trajectory holds a full block of memory time tau!", file=sys.stderr)
         sys.exit(1)
+    if srdist.world() > 1 and nV is None and v0 == 0:
+        # several ranks (torchrun): vectors are independent -- every rank computes its contiguous range of columns, all
+        # ranks receive the whole (lags, vectors) arrays
+        V = cat.shape[1]
+        i0, nloc = srdist.my_range(V)
+        L = F // 2
+        if nloc > 0:
+            Ct, dCt = _ctx(ctx).ct_palmer(cat, R, F, v0=i0, nV=nloc, chunk_start=starts, mode=mode)
+        else:
+            Ct, dCt = np.empty((L, 0)), np.empty((L, 0))
+        return srdist.gather_rows(Ct, V, axis=1), srdist.gather_rows(dCt, V, axis=1)
     return _ctx(ctx).ct_palmer(cat, R, F, v0=v0, nV=nV, chunk_start=starts, mode=mode)
 
 
@@ -103,7 +115,18 @@ def vector_distribution(vecs, q_rot=None, histBinX=72, delta_t=-1, tau_memory=-1
         Fb = 0
     else:
         Fb = int(tau_memory / delta_t)
-    hist, vecsum, outer = _ctx(ctx).rotate_hist(vecs, q_rot, edges[0], edges[1], v0=v0, nV=nV, block_len=Fb)
+    if srdist.world() > 1 and nV is None and v0 == 0:
+        V = vecs.shape[1]
+        i0, nloc = srdist.my_range(V)
+        if nloc > 0:
+            hist, vecsum, outer = _ctx(ctx).rotate_hist(vecs, q_rot, edges[0], edges[1], v0=i0, nV=nloc, block_len=Fb)
+        else:
+            nB = N // Fb if Fb else 1
+            hist, vecsum, outer = np.empty((0, histBinX, int(histBinX / 2))), np.empty((0, 3)), np.empty((nB, 0, 6))
+        hist, vecsum = srdist.gather_rows(hist, V, axis=0), srdist.gather_rows(vecsum, V, axis=0)
+        outer = srdist.gather_rows(outer, V, axis=1)
+    else:
+        hist, vecsum, outer = _ctx(ctx).rotate_hist(vecs, q_rot, edges[0], edges[1], v0=v0, nV=nV, block_len=Fb)
     mean = vecsum / N
     avgvec = mean / np.sqrt((mean ** 2).sum(-1))[..., np.newaxis]
     return dict(hist=hist, edges=edges, avgvec=avgvec, S2=S2_from_outer_sums(outer, Fb if Fb else N, blocked=bool(Fb)))

@@ -61,3 +61,124 @@ def gather_vector_axis(local, V, axis, device=None):
     if is_np:
         return full.cpu().numpy()
     return full
+
+
+# ---- helpers for the drop-in scripts: "am I one of several ranks, which rows are mine, give everybody everything" ----
+def _dist_or_none():
+    """torch.distributed when a process group is up, None otherwise -- without importing torch for a plain single run."""
+    import os
+    import sys
+    if int(os.environ.get('WORLD_SIZE', '1')) <= 1 and 'torch.distributed' not in sys.modules:
+        return None
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def world():
+    d = _dist_or_none()
+    return d.get_world_size() if d is not None else 1
+
+
+def rank():
+    d = _dist_or_none()
+    return d.get_rank() if d is not None else 0
+
+
+def is_root():
+    return rank() == 0
+
+
+def local_device():
+    """GPU of this rank: SPINRELAX_DEVICE if set (rehearsals with several ranks on one GPU), else LOCAL_RANK, else 0."""
+    import os
+    return int(os.environ.get('SPINRELAX_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+
+
+def start(backend=None):
+    """Called first thing by the drop-in scripts: under torchrun (WORLD_SIZE > 1) join the process group -- RCCL when every
+    rank has its own GPU, gloo when SPINRELAX_DIST_BACKEND=gloo or several ranks share a device -- otherwise do nothing.
+    Returns (rank, world)."""
+    import os
+    if int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        return 0, 1
+    return init_from_env(backend or os.environ.get('SPINRELAX_DIST_BACKEND'))
+
+
+def finish():
+    import shutil
+    while _SCRATCH:
+        shutil.rmtree(_SCRATCH.pop(), ignore_errors=True)
+    d = _dist_or_none()
+    if d is not None:
+        d.barrier()
+        d.destroy_process_group()
+
+
+def my_range(n):
+    """Rows [i0, i0 + nloc) of this rank out of n (everything when not distributed)."""
+    return shard_range(n, rank(), world())
+
+
+def _collective_device():
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend() == 'nccl':
+        return torch.device('cuda', local_device())
+    return None
+
+
+def gather_rows(local, n, axis=0):
+    """Every rank hands in its my_range(n) slice of an array along `axis` and receives the whole array."""
+    if world() == 1:
+        return local
+    return gather_vector_axis(np.ascontiguousarray(local), n, axis, device=_collective_device())
+
+
+_SCRATCH = []
+
+
+def output_prefix(out_pref):
+    """The output prefix a drop-in script should write to: rank 0 the user's, every other rank a private scratch directory
+    that finish() removes -- all ranks run the same code down to the writers, one set of reference-named files appears."""
+    if is_root():
+        return out_pref
+    import os
+    import tempfile
+    d = tempfile.mkdtemp(prefix='spinrelax_rank%d_' % rank())
+    _SCRATCH.append(d)
+    return os.path.join(d, os.path.basename(out_pref) or 'out')
+
+
+def relax(ctx, model, D, omega, f_DD, f_CSA, time_fact, gamma_ratio, S2, C, tau, nComps, binvecs=None, weights=None,
+          resvecs=None, noe_mode=0, want_J=False, weights_dev_ptr=None, want_stats=False):
+    """Context.relax (sr_jomega_relax_f64) over ALL residues with the residues split across the ranks of the process group:
+    every argument indexed by residue is sliced to this rank's range, the (E, nRes, ...) results are all-gathered, every
+    rank returns the complete arrays.  Global-parameter fits (--opt Diso | Daniso | zeta | CSA: scipy's Powell on a chi^2
+    over all residues, spectral_densities.py:1360-1369, calculate-relaxations-from-Ct.py:865-1000) therefore evaluate the
+    SAME objective value on every rank and walk the same path in lock-step; the exchange per objective call is this one
+    all-gather of E x nRes x 8 doubles (SURVEY.md section 8(e) allows either that or an all-reduce of E partial chi^2
+    sums -- the gather keeps the summation order, hence the optimiser's path, independent of the number of ranks).
+    Single process: a plain call."""
+    kw = dict(binvecs=binvecs, weights=weights, resvecs=resvecs, noe_mode=noe_mode, want_J=want_J, want_stats=want_stats)
+    if world() == 1:
+        return ctx.relax(model, D, omega, f_DD, f_CSA, time_fact, gamma_ratio, S2, C, tau, nComps, weights_dev_ptr=weights_dev_ptr, **kw)
+    if weights_dev_ptr:
+        raise ValueError('dist.relax: device-resident weights belong to one rank; pass host weights when several ranks share the residues')
+    S2 = np.asarray(S2, dtype=np.float64)
+    n = S2.size
+    omega = np.atleast_2d(np.asarray(omega, dtype=np.float64))
+    E = omega.shape[0]
+    i0, nloc = my_range(n)
+    sl = slice(i0, i0 + nloc)
+    f_CSA = np.broadcast_to(np.asarray(f_CSA, dtype=np.float64), (E, n))
+    C = np.atleast_2d(np.asarray(C, dtype=np.float64))
+    tau = np.atleast_2d(np.asarray(tau, dtype=np.float64))
+    if nloc > 0:
+        kw['weights'] = None if weights is None else np.asarray(weights)[sl]
+        kw['resvecs'] = None if resvecs is None else np.asarray(resvecs)[sl]
+        res = ctx.relax(model, D, omega, f_DD, f_CSA[:, sl], time_fact, gamma_ratio, S2[sl], C[sl], tau[sl],
+                        np.asarray(nComps)[sl], **kw)
+    else:
+        res = (np.empty((E, 0, 4, 2)), np.empty((E, 0, 5, 2)) if want_J else None) + ((np.empty((E, 0, 12)),) if want_stats else ())
+    out = [None if r is None else gather_rows(r, n, axis=1) for r in res]
+    return tuple(out)

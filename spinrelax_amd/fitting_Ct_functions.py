@@ -14,6 +14,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import hip
+from . import dist as srdist
 
 GREEK = np.array(['a', 'b', 'g', 'd', 'e', 'z', 'h'])      # fitting_Ct_functions.py:136
 
@@ -417,7 +418,30 @@ def order_search_device(t, y, dy, listDoG=(2, 3, 5, 7, 9), chiSqThreshold=0.5, c
     tau_max = t[0, -1] * 10                      # fitting_Ct_functions.py:324 (per-residue axes share their end point)
     if not np.all(t[:, -1] == t[0, -1]):
         raise ValueError('order_search_device: residues with different final times need separate calls (tau bound)')
-    return _ctx(ctx).order_search(t, y, dy, listDoG, tau_guesses(t, listDoG), tau_max, chiSqThreshold)
+    tg = tau_guesses(t, listDoG)
+    n = y.shape[0]
+    if srdist.world() == 1:
+        return _ctx(ctx).order_search(t, y, dy, listDoG, tg, tau_max, chiSqThreshold)
+    # several ranks (torchrun): residues are independent, every rank solves its contiguous range and all ranks receive
+    # all results (no data-path collective, one gather of the results)
+    i0, nloc = srdist.my_range(n)
+    sl = slice(i0, i0 + nloc)
+    if nloc > 0:
+        loc = _ctx(ctx).order_search(t[sl], y[sl], None if dy is None else np.asarray(dy)[sl], listDoG,
+                                     tg if np.ndim(tg) < 2 or tg.shape[0] == 1 else tg[sl], tau_max, chiSqThreshold)
+    else:
+        nO, Pmax = len(listDoG), max(listDoG)
+        loc = dict(popt=np.empty((nO, 0, Pmax)), dP=np.empty((nO, 0, Pmax)), chisq=np.empty((nO, 0)),
+                   status=np.empty((nO, 0), dtype=np.int32), nfev=np.empty((nO, 0), dtype=np.int32), best=np.empty(0, dtype=np.int32),
+                   S2=np.empty(0), C=np.empty((0, Pmax // 2)), tau=np.empty((0, Pmax // 2)), chi=np.empty(0), K=np.empty(0, dtype=np.int32))
+    out = {}
+    for k, v in loc.items():
+        if k == 'orders':
+            out[k] = v
+            continue
+        out[k] = srdist.gather_rows(v, n, axis=1 if k in ('popt', 'dP', 'chisq', 'status', 'nfev') else 0)
+    out.setdefault('orders', np.ascontiguousarray(listDoG, dtype=np.int32))
+    return out
 
 
 def order_search_device_results(t, y, dy, listDoG=(2, 3, 5, 7, 9), chiSqThreshold=0.5, ctx=None):

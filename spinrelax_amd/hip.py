@@ -6,6 +6,7 @@ numpy-facing wrapper around the C ABI (spinrelax_amd/_lib.py -> libspinrelax_hip
 ``tensor.data_ptr()``) and only enqueue work on the context's stream.
 """
 import ctypes
+import sys
 
 import numpy as np
 
@@ -42,7 +43,6 @@ class Context:
             self.h = None
 
     def __del__(self):
-        import sys
         if sys is None or sys.is_finalizing():
             return
         try:
@@ -400,8 +400,12 @@ import atexit as _atexit      # noqa: E402
 _atexit.register(_close_default_contexts)      # teardown while the HIP runtime is still alive, not from __del__ at exit
 
 
-def default_context(device=0):
-    """Process-wide context per device (created on first use)."""
+def default_context(device=None):
+    """Process-wide context per device (created on first use).  Without an explicit device: SPINRELAX_DEVICE, else the
+    LOCAL_RANK torchrun sets (one rank per GPU), else 0."""
+    if device is None:
+        import os
+        device = int(os.environ.get('SPINRELAX_DEVICE', os.environ.get('LOCAL_RANK', '0')))
     if device not in _default or _default[device].h is None:
         _default[device] = Context(device)
     return _default[device]

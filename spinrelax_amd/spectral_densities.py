@@ -12,6 +12,7 @@ import sys
 import numpy as np
 
 from . import hip
+from . import dist as srdist
 from . import _hostmath as _nph
 
 # spectral_densities.py:50-67, :39-48
@@ -250,7 +251,7 @@ def _run(RObj, nSites, S2, consts, taus, vecXH, weights, CSAvaluesArray, want_J,
             kw = dict(binvecs=vecXH[0], weights=weights, weights_dev_ptr=weights_dev_ptr)
         else:
             kw = dict(resvecs=vecXH)
-    out, J = _ctx(ctx).relax(model, D, RObj.omega, RObj.get_f_DD(), fcsa[None, :], RObj.time_fact,
+    out, J = srdist.relax(_ctx(ctx), model, D, RObj.omega, RObj.get_f_DD(), fcsa[None, :], RObj.time_fact,
                              RObj.gH.gamma / RObj.gX.gamma, S2a, C, T, K, noe_mode=0, want_J=want_J, **kw)
     return out[0], (J[0] if J is not None else None), dist
 

@@ -18,6 +18,7 @@ import numpy as np
 from scipy.optimize import fmin_powell
 
 from . import hip
+from . import dist as srdist
 from . import _hostmath as hm
 from . import general_scripts as gs
 from . import fitting_Ct_functions as fitCt
@@ -474,7 +475,7 @@ class spinRelaxationExperiments:
     def eval_all(self, ind=None, bVerbose=False, ctx=None):
         """spectral_densities.py:1145-1157 for every experiment at once.  `ind`: update only that residue's entries."""
         args, kw = self._kernel_inputs()
-        out, _ = _ctx(ctx or self.ctx).relax(*args, noe_mode=1, **kw)
+        out, _ = srdist.relax(_ctx(ctx or self.ctx), *args, noe_mode=1, **kw)
         for e, sp in enumerate(self.spinrelax):
             v = out[e, :, sp.column, 0]
             err = out[e, :, sp.column, 1] if self.globalRotDif.axisAvg is not None else None
@@ -547,7 +548,7 @@ class spinRelaxationExperiments:
     def rscsa_statistics(self, ctx=None):
         """One launch: per (experiment, residue) the 12 sufficient statistics of the CSA dependence."""
         args, kw = self._kernel_inputs()
-        _, _, stats = _ctx(ctx or self.ctx).relax(*args, noe_mode=1, want_stats=True, **kw)
+        _, _, stats = srdist.relax(_ctx(ctx or self.ctx), *args, noe_mode=1, want_stats=True, **kw)
         return stats
 
     def rscsa_closed_form(self, stats, e, i, csa):
@@ -574,7 +575,9 @@ class spinRelaxationExperiments:
         reference, the CSA kept for a residue is the one of the LAST objective evaluation (the reference ignores
         fmin_powell's return value and relies on the side effect of set_all_csa inside the objective)."""
         stats = self.rscsa_statistics()
-        for i in range(self.localCtModels.nModels):
+        n = self.localCtModels.nModels
+        i0, nloc = srdist.my_range(n)            # several ranks: each searches its residues, results gathered below
+        for i in range(i0, i0 + nloc):
             cover = self.mapExptCoverage[i]
             if len(cover) == 0:
                 continue
@@ -601,6 +604,14 @@ class spinRelaxationExperiments:
                 return chisq / len(cover)
             fmin_powell(objective, x0=self.get_first_csa(ind=i), direc=[spinRelaxationExperiments.dictStepSizes['rsCSA']],
                         full_output=False, disp=False)
+        if srdist.world() > 1:
+            sl = slice(i0, i0 + nloc)
+            csa = srdist.gather_rows(np.array(self.get_first_csa())[sl], n)
+            for sp in self.spinrelax:
+                sp.angFreq.gA.set_csa(csa)
+                sp.values = srdist.gather_rows(np.asarray(sp.values)[sl], n)
+                if sp.errors is not None:
+                    sp.errors = srdist.gather_rows(np.asarray(sp.errors)[sl], n)
 
     def perform_optimisation(self, maxCycles=10, tol=1e-6):
         """spectral_densities.py:1302-1358."""

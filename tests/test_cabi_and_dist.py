@@ -112,3 +112,58 @@ def test_two_rank_gloo_shard_and_gather(tmp_path, V):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, 'rank %d failed:\n%s' % (r, out)
         assert 'rank %d ok' % r in out
+
+
+def _relax_worker(rank, world, port, q):
+    import os
+    import numpy as np
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    from spinrelax_amd import dist as srdist
+
+    class FakeCtx:                       # stands in for hip.Context.relax: a residue-wise function of its inputs
+        def relax(self, model, D, omega, f_DD, f_CSA, time_fact, gamma_ratio, S2, C, tau, nComps, binvecs=None, weights=None,
+                  resvecs=None, noe_mode=0, want_J=False, weights_dev_ptr=None, want_stats=False):
+            E, n = np.atleast_2d(omega).shape[0], len(S2)
+            base = np.asarray(S2)[None, :, None, None] + np.asarray(f_CSA)[:, :, None, None] + np.asarray(weights).sum(axis=1)[None, :, None, None]
+            out = base + np.arange(8).reshape(4, 2)[None, None]
+            J = out[:, :, :, :1].repeat(5, axis=2)[:, :, :5] if want_J else None
+            return (out, J, out.reshape(E, n, 8).repeat(2, axis=2)[:, :, :12]) if want_stats else (out, J)
+    n, E = 7, 3
+    rng = np.random.default_rng(3)
+    S2, fcsa, w = rng.random(n), rng.random((E, n)), rng.random((n, 5))
+    C, tau, K = rng.random((n, 2)), rng.random((n, 2)), np.full(n, 2)
+    args = (2, [1.0, 2.0], rng.random((E, 5)), np.ones(E), fcsa, np.ones(E), np.ones(E), S2, C, tau, K)
+    got = srdist.relax(FakeCtx(), *args, binvecs=np.zeros((5, 3)), weights=w, want_stats=True)
+    i0, nloc = srdist.my_range(n)
+    rows = srdist.gather_rows(np.arange(n * 2.0).reshape(n, 2)[i0:i0 + nloc], n)
+    q.put((rank, [None if g is None else g.copy() for g in got], rows, srdist.world(), srdist.is_root(), srdist.output_prefix('/x/out')))
+    srdist.finish()
+
+
+def test_distributed_relax_and_row_gather_three_ranks():
+    """spinrelax_amd.dist.relax / gather_rows with 3 gloo ranks and 7 residues (uneven shards 3/2/2): every rank receives
+    exactly what one process computes; only rank 0 keeps the user's output prefix."""
+    import multiprocessing as mp
+    import numpy as np
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    world, port = 3, 29733
+    ps = [ctx.Process(target=_relax_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, E = 7, 3
+    rng = np.random.default_rng(3)
+    S2, fcsa, w = rng.random(n), rng.random((E, n)), rng.random((n, 5))
+    base = S2[None, :, None, None] + fcsa[:, :, None, None] + w.sum(axis=1)[None, :, None, None]
+    want = base + np.arange(8).reshape(4, 2)[None, None]
+    for rank, got, rows, wd, root, pref in res:
+        assert wd == 3 and root == (rank == 0)
+        assert np.array_equal(got[0], want) and got[1] is None and got[2].shape == (E, n, 12)
+        assert np.array_equal(rows, np.arange(n * 2.0).reshape(n, 2))
+        assert (pref == '/x/out') == (rank == 0) and pref.endswith('out')

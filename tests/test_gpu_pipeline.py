@@ -221,13 +221,31 @@ def test_bench_json_contract():
     assert j['unit'] == 'triples/s' and j['data'] == 'synthetic' and j['vs_baseline'] is None and 'workload' in j['config']
     assert abs(j['value'] - j['config']['exact_triples_per_gpu'] / (j['ms_per_step'] * 1e-3)) <= 1e-6 * j['value']
     r = j['roofline']
-    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernel_ms', 'executed'):
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernel_ms', 'selection', 'direct_equivalent'):
         assert k in r, k
-    assert r['kernel'] == 'k_ct_fft' and 0 < r['kernel_ms'] < j['ms_per_step'] * 1.05
-    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
-    assert 0 < r['executed']['frac'] < 1 and r['executed']['fraction_of_direct_flop'] < 0.1
+    # every fraction is a fraction of a bound its kernel can reach: in (0, 1]
+    ks = j['kernels']
+    assert r['kernel'] in ks and set(ks) >= {'k_ct_fft', 'k_ct_palmer', 'k_vechist', 'k_pack_soa', 'k_order_search'}
+    top = ks[r['kernel']]
+    assert top['cu_ms_per_batch'] == max(v['cu_ms_per_batch'] for k, v in ks.items() if k != 'k_ct_palmer')
+    for name, e in ks.items():
+        for f in ('frac', 'frac_alone'):
+            if e.get(f) is not None:
+                assert 0 < e[f] <= 1.0, (name, f, e[f])
+    if r['frac'] is not None:
+        assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0 < r['frac'] <= 1
+    ct = ks['k_ct_fft']
+    assert 0 < ct['in_pipeline_ms'] < j['ms_per_step'] * 1.05 and ct['alone_ms'] <= ct['in_pipeline_ms'] * 1.05
+    assert abs(ct['frac'] - ct['work_per_launch'] / (ct['in_pipeline_ms'] * 1e-3) / 1e12 / ct['peak']) < 1e-9
+    assert ct['work_per_launch'] < 0.1 * 8 * j['config']['exact_triples_per_gpu']          # the FFT executes < 10 % of the direct flop
+    vh = ks['k_vechist']
+    assert vh['bound'] == 'hbm' and abs(vh['achieved'] - vh['work_per_launch'] / (vh['in_pipeline_ms'] * 1e-3) / 1e9) < 1e-6 * vh['achieved']
+    fit = ks['k_order_search']
+    assert fit['residues_per_s'] > 0 and fit['evaluations_per_s'] > fit['residues_per_s'] and fit['saturated_ms_per_batch'] <= fit['alone_ms']
+    assert j['latency_ms']['min'] >= j['ms_per_step'] * 0.9          # one batch alone cannot beat the pipelined period by much
     c = j['cpu_baseline']
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k
     assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0
+    assert set(c['stages_s']) >= {'ct_s', 'rotate_hist_s', 'fit_s', 'relax_s'} and c['all_cores']['cores'] >= 1 and 'cpu_fft_formulation' in c
     assert j['fit']['unfitted'] == 0

@@ -61,7 +61,7 @@ sr_ctx *sr_create(int device)
     ctx->stream = nullptr;
     ctx->fit_waves = 4;
     ctx->fit_lds = 1;
-    ctx->ct_fft = 1;
+    ctx->ct_fft = 2;
     ctx->fft_table_ready = 0;
     if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) {
         sr_set_error("hipGetDeviceProperties failed");
@@ -103,7 +103,7 @@ int sr_set_option(sr_ctx *ctx, const char *name, int value)
         return 0;
     }
     if (!strcmp(name, "ct_fft")) {
-        SR_REQUIRE(value == 0 || value == 1, -3, "sr_set_option: ct_fft must be 0 or 1");
+        SR_REQUIRE(value >= 0 && value <= 2, -3, "sr_set_option: ct_fft must be 0, 1 or 2");
         ctx->ct_fft = value;
         return 0;
     }

@@ -391,6 +391,29 @@ __device__ __forceinline__ cplx mul_w32(cplx d)
     return {fma(d.re, c[E], d.im * s[E]), fma(d.im, c[E], -(d.re * s[E]))};
 }
 
+// d * exp(-2 pi i e / 32) for e = 0..15 known after unrolling (a switch the optimiser folds)
+__device__ __forceinline__ cplx mul_w32_rt(cplx d, int e)
+{
+    switch (e) {
+        case 0: return mul_w32<0>(d);
+        case 1: return mul_w32<1>(d);
+        case 2: return mul_w32<2>(d);
+        case 3: return mul_w32<3>(d);
+        case 4: return mul_w32<4>(d);
+        case 5: return mul_w32<5>(d);
+        case 6: return mul_w32<6>(d);
+        case 7: return mul_w32<7>(d);
+        case 8: return mul_w32<8>(d);
+        case 9: return mul_w32<9>(d);
+        case 10: return mul_w32<10>(d);
+        case 11: return mul_w32<11>(d);
+        case 12: return mul_w32<12>(d);
+        case 13: return mul_w32<13>(d);
+        case 14: return mul_w32<14>(d);
+        default: return mul_w32<15>(d);
+    }
+}
+
 template <int LOGN, int S, int BLK, int J>
 struct FftStage {
     __device__ static __forceinline__ void run(cplx *v)
@@ -504,17 +527,27 @@ __device__ __forceinline__ void apply_twiddles(cplx *v, cplx base)
 __host__ __device__ constexpr int fft_pad(int a) { return a + (a >> 3) + 8 * (a >> 8); }
 __host__ __device__ constexpr int fft_lds_slots(int M) { return M + (M >> 3) + 8 * (M >> 8); }
 
-// tab[2t], tab[2t+1] = cos, -sin of 2 pi t / 8192 for t < 1024, followed by the same for 2 pi t / 6144, t < 256
+// tab[2t], tab[2t+1] = cos, -sin of 2 pi t / 8192 for t < 1024, followed by the same for 2 pi t / 6144, t < 256 (k_ct_fft);
+// then, from complex index 1280, the three 256-entry tables of k_ct_rfft for N1 = 12 and for N1 = 16:
+//   w_H^t (H = 256 N1), w_256^t, w_M^t (M = 512 N1)
+constexpr int kFftTabDoubles = 2 * (1280 + 2 * 768);
 __global__ void k_fft_init_table(double *tab)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double sn, cs;
     if (t < 1280) {
-        double sn, cs;
         if (t < 1024) sincospi((double)t / 4096.0, &sn, &cs);
         else sincospi((double)(t - 1024) / 3072.0, &sn, &cs);
-        tab[2 * t] = cs;
-        tab[2 * t + 1] = -sn;
+    } else if (t < 1280 + 2 * 768) {
+        const int u = t - 1280, set = u / 768, j = u - set * 768, which = j >> 8, i = j & 255;
+        const double H = set == 0 ? 3072.0 : 4096.0;
+        const double len = which == 0 ? H : (which == 1 ? 256.0 : 2.0 * H);
+        sincospi(2.0 * (double)i / len, &sn, &cs);
+    } else {
+        return;
     }
+    tab[2 * t] = cs;
+    tab[2 * t + 1] = -sn;
 }
 
 struct CtFftArgs {
@@ -714,6 +747,278 @@ int launch_ct_fft(sr_ctx *ctx, const CtFftArgs &a, int64_t series)
     return a.F <= 256 * NZ ? launch_ct_fft_h<N1, true>(ctx, a, series) : launch_ct_fft_h<N1, false>(ctx, a, series);
 }
 
+// ------------------------------------------------------------------------------------------
+// kernel 1, REAL-input FFT formulation (production for 4096 < F + L <= 8192)
+// ------------------------------------------------------------------------------------------
+// Same mathematics as k_ct_fft (six autocorrelations by Wiener-Khinchin, float64), restructured around occupancy: the six
+// signals are real, so each goes through a complex transform of HALF the padded length (z[m] = a[2m] + i a[2m+1],
+// H = M/2 points) and the real even power spectrum comes back through ONE half-length transform.  The LDS image of a
+// transform shrinks from 96 KB to 52 KB (H = 3072): THREE workgroups share a CU's 160 KB instead of one, at <= 168
+// registers per lane -- k_ct_fft runs at one wave per SIMD (256 VGPR + 196 AGPR) and is latency-bound.  Seven half-length
+// transforms per series replace four full-length ones (20 % fewer flop).
+//
+// H = N1 * 256 (N1 = 12: M = 6144, the F = 4096 chunks; N1 = 16: M = 8192), 256 threads, three steps N1 x 16 x 16 with
+// every small transform in registers:
+//   1. thread n2 holds z[n2 + 256 n1], n1 < N1: N1-point transform (12 = 3 x 4), twiddle w_H^(n2 k1), to LDS as
+//      element k1*256 + n2 (one pad slot per 16);
+//   2. thread (k1, lo), k1 < N1 (16 N1 of the 256 threads): 16-point transform over h (n2 = lo + 16 h), twiddle
+//      w_256^(lo k2a), to LDS row (k1*16 + k2a), column lo (rows of 17 slots);
+//   3. thread (k1, k2a): reads its own row, 16-point transform over lo: X[k1 + N1 (k2a + 16 k2b)], k2b < 16.
+// Real-signal spectrum from Z = FFT_H(z):  A[k] = (Z[k] + conj Z[H-k])/2 - (i/2) w_M^k (Z[k] - conj Z[H-k]); the partner
+// frequency H - k lives in thread (N1-k1, 15-k2a) at 15-k2b (k1 = 0 apart), fetched through the row layout.
+// Back: with P[k] the weighted power spectrum (P[M-k] = P[k]),  Y[k] = (P[k] + P[H-k]) + i (P[k] - P[H-k]) conj(w_M^k);
+// FFT_H(Y)[m] = M (S[2m] + i S[2m-1]): the even lags in the real part, the odd ones in the imaginary part.
+// All LDS accesses are 16-byte (one complex) and conflict-free for the lane groups of ds_read_b128 / ds_write_b128
+// (MI355X_MICROARCH.md, LDS) except a 2-way case in the natural-order read of Y.
+template <int N1>
+struct RStage1 {                                           // N1 = 16
+    __host__ __device__ static constexpr int k1(int p) { return bitrev<4>(p); }
+    __device__ static __forceinline__ void run(cplx *v) { fft_reg<4>(v); }
+};
+template <int B>
+__device__ __forceinline__ void dft3_col12(cplx *v, cplx (*y)[4])
+{
+    constexpr double h = 0.8660254037844386;            // sqrt(3)/2
+    const cplx x0 = v[B], x1 = v[4 + B], x2 = v[8 + B];
+    const cplx t = {x1.re + x2.re, x1.im + x2.im}, d = {x1.re - x2.re, x1.im - x2.im};
+    const cplx m = {fma(-0.5, t.re, x0.re), fma(-0.5, t.im, x0.im)};
+    const cplx r = {h * d.im, -h * d.re};                // -i sqrt(3)/2 (x1 - x2)
+    y[0][B] = {x0.re + t.re, x0.im + t.im};
+    y[1][B] = mul_w24<2 * B>(cplx{m.re + r.re, m.im + r.im});          // w_12^B
+    y[2][B] = mul_w24<4 * B>(cplx{m.re - r.re, m.im - r.im});          // w_12^(2B)
+    if constexpr (B + 1 < 4) dft3_col12<B + 1>(v, y);
+}
+template <>
+struct RStage1<12> {                                       // n1 = 4 a + b, k1 = ka + 3 kb
+    __host__ __device__ static constexpr int k1(int p) { return (p >> 2) + 3 * bitrev<2>(p & 3); }
+    __device__ static __forceinline__ void run(cplx *v)
+    {
+        cplx y[3][4];
+        dft3_col12<0>(v, y);
+#pragma unroll
+        for (int ka = 0; ka < 3; ++ka) {
+            fft_reg<2>(y[ka]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[4 * ka + q] = y[ka][q];
+        }
+    }
+};
+
+// v[p] *= base^k(p): the powers are built one after the other (k = 1 .. N-1), no table of N powers in registers
+template <int N, class KOF>
+__device__ __forceinline__ void apply_twiddles_seq(cplx *v, cplx base)
+{
+    cplx cur = base;
+#pragma unroll
+    for (int k = 1; k < N; ++k) {
+#pragma unroll
+        for (int p = 0; p < N; ++p)
+            if (KOF::k1(p) == k) v[p] = cmul(v[p], cur);
+        if (k + 1 < N) cur = cmul(cur, base);
+    }
+}
+
+struct CtRfftArgs {
+    const float *soa;
+    int64_t Npad;
+    const int64_t *chunk_start;   // device, may be null
+    const double *tab;            // 3 x 256 complex: w_H^t, w_256^t, w_M^t
+    double *psum;                 // (nV, R, Lp)
+    int R, F, L, Lp;
+};
+
+__host__ __device__ constexpr int rfft_lds_slots(int N1) { return 256 * N1 + 256 * N1 / N1 + 16; }   // natural order, one pad per N1
+
+// One half-length transform: the thread's N1 inputs v[] (natural order, element tid + 256 n1) -> for the 16 N1 threads
+// (k1, k2a) = (tid >> 4, tid & 15), k1 < N1: w[p] = X[k1 + N1 (k2a + 16 rev4(p))].  The caller has made sure nobody still
+// reads the LDS image; on return every thread has read what it needs from it (row tid is the thread's own).
+template <int N1>
+__device__ __forceinline__ void rfft_workgroup(cplx *v, cplx *w, cplx *lds, const double *__restrict__ tab, int tid)
+{
+    RStage1<N1>::run(v);
+    apply_twiddles_seq<N1, RStage1<N1>>(v, cplx{tab[2 * tid], tab[2 * tid + 1]});
+    {
+        cplx *b = lds + tid + (tid >> 4);                         // element k1*256 + tid, one pad slot per 16
+#pragma unroll
+        for (int p = 0; p < N1; ++p) b[272 * RStage1<N1>::k1(p)] = v[p];
+    }
+    __syncthreads();
+    const int k1 = tid >> 4, lo = tid & 15;
+    const bool act = k1 < N1;
+    cplx u[16];
+    if (act) {
+        const cplx *b = lds + 272 * k1 + lo;                      // element k1*256 + lo + 16 h -> + 17 h
+#pragma unroll
+        for (int h = 0; h < 16; ++h) u[h] = b[17 * h];
+        fft_reg<4>(u);
+        apply_twiddles_seq<16, RStage1<16>>(u, cplx{tab[2 * (256 + lo)], tab[2 * (256 + lo) + 1]});
+    }
+    __syncthreads();
+    if (act) {
+        cplx *b = lds + 272 * k1 + lo;                            // row (k1*16 + k2a) of 17 slots, column lo
+#pragma unroll
+        for (int p = 0; p < 16; ++p) b[17 * bitrev<4>(p)] = u[p];
+    }
+    __syncthreads();
+    if (act) {
+        const cplx *b = lds + 17 * tid;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) w[e] = b[e];
+        fft_reg<4>(w);
+    }
+}
+
+// HALF: the chunk fills at most 2/3 (N1 = 12) or 1/2 (N1 = 16) of the padded length: the thread's inputs beyond NZ are
+// known to be zero and are neither loaded nor multiplied
+template <int N1, bool HALF>
+__global__ __launch_bounds__(256, N1 == 12 ? 3 : 2) void k_ct_rfft(CtRfftArgs a)
+{
+    extern __shared__ __align__(16) unsigned char fft_smem[];
+    cplx *lds = reinterpret_cast<cplx *>(fft_smem);
+    constexpr int H = N1 * 256, M = 2 * H;
+    constexpr int NZ = HALF ? (N1 == 12 ? 8 : N1 / 2) : N1;
+    const int tid = threadIdx.x;
+    const int v = blockIdx.x / a.R, r = blockIdx.x - v * a.R;
+    const int F = a.F;
+    const int64_t start = a.chunk_start ? a.chunk_start[r] : (int64_t)r * F;
+    const float *px = a.soa + ((int64_t)v * 3 + 0) * a.Npad + start;
+    const int k1 = tid >> 4, k2a = tid & 15;
+    const bool act = k1 < N1;
+    // partner thread holding the frequencies H - k (see the header comment); thread 0 pairs k2b with (16 - k2b) & 15
+    const int pt = k1 != 0 ? (N1 - k1) * 16 + (15 - k2a) : (k2a != 0 ? 16 - k2a : 0);
+    const bool z0 = tid == 0;
+    const cplx wbase = {a.tab[2 * (512 + (act ? k1 + N1 * k2a : 0))], a.tab[2 * (512 + (act ? k1 + N1 * k2a : 0)) + 1]};   // w_M^(k1 + N1 k2a)
+
+    double W[16], WH = 0.0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) W[p] = 0.0;
+
+#pragma unroll 1
+    for (int c = 0; c < 6; ++c) {
+        // signal c = x^2, y^2, z^2, xy, xz, yz: product of two of the three planes
+        asm volatile("" ::: "memory");
+        const int ia = c < 3 ? c : (c == 5 ? 1 : 0), ib = c < 3 ? c : (c == 3 ? 1 : 2);
+        const float *pa = px + (int64_t)ia * a.Npad, *pb = px + (int64_t)ib * a.Npad;
+        float ar[2 * N1], br[2 * N1];
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) {
+            if (n1 >= NZ) {
+                ar[2 * n1] = ar[2 * n1 + 1] = br[2 * n1] = br[2 * n1 + 1] = 0.f;
+                continue;
+            }
+            const int f0 = 2 * (tid + 256 * n1), f1 = f0 + 1;
+            const bool in0 = f0 < F, in1 = f1 < F;
+            const int c0 = in0 ? f0 : 0, c1 = in1 ? f1 : 0;       // clamped unconditional loads + select (no branch per sample)
+            const float a0 = pa[c0], a1 = pa[c1], b0 = pb[c0], b1 = pb[c1];
+            ar[2 * n1] = in0 ? a0 : 0.f; ar[2 * n1 + 1] = in1 ? a1 : 0.f;
+            br[2 * n1] = in0 ? b0 : 0.f; br[2 * n1 + 1] = in1 ? b1 : 0.f;
+        }
+        cplx sig[N1];
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1)
+            sig[n1] = {(double)ar[2 * n1] * (double)br[2 * n1], (double)ar[2 * n1 + 1] * (double)br[2 * n1 + 1]};
+        cplx w[16];
+        rfft_workgroup<N1>(sig, w, lds, a.tab, tid);
+        // own row again, now in frequency order k2b; then every thread reads the partner frequencies
+        if (act) {
+            cplx *b = lds + 17 * tid;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) b[bitrev<4>(p)] = w[p];
+        }
+        __syncthreads();
+        if (act) {
+            const double wgt = c < 3 ? 0.25 : 0.5;                // weight / 4
+            const cplx *b = lds + 17 * pt;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                constexpr int dummy = 0; (void)dummy;
+                const int k2b = bitrev<4>(p);
+                const cplx zm = b[z0 ? ((16 - k2b) & 15) : 15 - k2b];
+                const cplx zk = w[p];
+                const cplx S = {zk.re + zm.re, zk.im - zm.im}, D = {zk.re - zm.re, zk.im + zm.im};
+                const cplx wk = mul_w32_rt(wbase, k2b);
+                const cplx T = cmul(wk, D);
+                const double are = S.re + T.im, aim = S.im - T.re;    // 2 A[k] = S - i w D
+                W[p] = fma(wgt, fma(are, are, aim * aim), W[p]);
+            }
+            if (z0) {
+                const double e = w[0].re - w[0].im;                    // A[H] = Re Z[0] - Im Z[0]
+                WH = fma(4.0 * wgt, e * e, WH);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- back: Y[k] = (P[k] + P[H-k]) + i (P[k] - P[H-k]) conj(w_M^k), through the same transform ----
+    if (act) {
+        cplx *b = lds + 17 * tid;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) b[bitrev<4>(p)] = {W[p], 0.0};
+    }
+    __syncthreads();
+    cplx Y[16];
+    if (act) {
+        const cplx *b = lds + 17 * pt;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int k2b = bitrev<4>(p);
+            double Pm = b[z0 ? ((16 - k2b) & 15) : 15 - k2b].re;
+            if (z0 && p == 0) Pm = WH;                                 // k = 0: P[H - 0] = P[H]
+            const double E = W[p] + Pm, d = W[p] - Pm;
+            const cplx wk = mul_w32_rt(wbase, k2b);                    // (cos, -sin)
+            Y[p] = {fma(d, wk.im, E), d * wk.re};                      // E + i d conj(wk) = (E - d sin, d cos), wk.im = -sin
+        }
+    }
+    __syncthreads();
+    if (act) {
+        // natural order k = k1 + N1 (k2a + 16 k2b), one pad slot per N1 elements: k + k2a + 16 k2b
+        cplx *b = lds + k1 + (N1 + 1) * k2a;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) b[16 * (N1 + 1) * bitrev<4>(p)] = Y[p];
+    }
+    __syncthreads();
+    {
+        cplx sig[N1];
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) {
+            const int k = tid + 256 * n1;
+            sig[n1] = lds[k + k / N1];
+        }
+        __syncthreads();
+        cplx w[16];
+        rfft_workgroup<N1>(sig, w, lds, a.tab, tid);
+        if (act) {
+            double *out = a.psum + ((int64_t)v * a.R + r) * a.Lp;
+            const double inv = 1.0 / (double)M;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int m = k1 + N1 * (k2a + 16 * bitrev<4>(p));
+                const int le = 2 * m, lod = 2 * m - 1;
+                if (le >= 1 && le <= a.L) out[le] = w[p].re * inv;
+                if (lod >= 1 && lod <= a.L) out[lod] = w[p].im * inv;
+            }
+        }
+    }
+}
+
+template <int N1, bool HALF>
+int launch_ct_rfft_h(sr_ctx *ctx, const CtRfftArgs &a, int64_t series)
+{
+    const size_t lds = (size_t)rfft_lds_slots(N1) * sizeof(cplx);
+    if (lds > 64 * 1024)
+        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ct_rfft<N1, HALF>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_ct_rfft<N1, HALF>), dim3((unsigned)series), dim3(256), lds, ctx->stream, a);
+    SR_HIP(hipGetLastError());
+    return 0;
+}
+template <int N1>
+int launch_ct_rfft(sr_ctx *ctx, const CtRfftArgs &a, int64_t series)
+{
+    constexpr int NZ = N1 == 12 ? 8 : N1 / 2;
+    return a.F <= 512 * NZ ? launch_ct_rfft_h<N1, true>(ctx, a, series) : launch_ct_rfft_h<N1, false>(ctx, a, series);
+}
+
 // mean / std over the R replicate chunks, calculate-Ct-from-traj.py:226-228
 __global__ __launch_bounds__(256) void k_ct_finalize(const double *__restrict__ psum, int R, int F, int L, int Lp,
                                                      int64_t nV, double *__restrict__ Ct, double *__restrict__ dCt)
@@ -864,13 +1169,25 @@ int sr_ct_palmer_sums_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64
     // FFT formulation: chunk + lags must fit a 2048 / 4096 / 8192-point transform (shorter chunks are cheap anyway)
     const int64_t need = F + L;
     if (mode == 0 && ctx->ct_fft && need > 1024 && need <= 8192) {
-        double *tab = (double *)sr_workspace(ctx, SR_WS_FFT, 2560 * sizeof(double));
+        double *tab = (double *)sr_workspace(ctx, SR_WS_FFT, kFftTabDoubles * sizeof(double));
         if (!tab) return -5;
         if (!ctx->fft_table_ready) {
-            hipLaunchKernelGGL(k_fft_init_table, dim3(5), dim3(256), 0, ctx->stream, tab);
+            hipLaunchKernelGGL(k_fft_init_table, dim3((kFftTabDoubles / 2 + 255) / 256), dim3(256), 0, ctx->stream, tab);
             SR_HIP(hipGetLastError());
             SR_HIP(hipStreamSynchronize(ctx->stream));      // once per context: later launches may come on other streams
             ctx->fft_table_ready = 1;
+        }
+        if (ctx->ct_fft == 2 && need > 4096) {
+            // real-input formulation: half-length transforms, three workgroups per CU
+            CtRfftArgs ra;
+            ra.soa = soa; ra.Npad = Npad; ra.chunk_start = cs_dev; ra.psum = psum;
+            ra.R = (int)R; ra.F = (int)F; ra.L = (int)L; ra.Lp = (int)Lp;
+            if (need <= 6144) {
+                ra.tab = tab + 2 * 1280;
+                return launch_ct_rfft<12>(ctx, ra, series);
+            }
+            ra.tab = tab + 2 * (1280 + 768);
+            return launch_ct_rfft<16>(ctx, ra, series);
         }
         CtFftArgs fa;
         fa.soa = soa; fa.Npad = Npad; fa.chunk_start = cs_dev; fa.tab = tab; fa.psum = psum;

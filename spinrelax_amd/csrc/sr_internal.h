@@ -20,7 +20,8 @@ struct sr_ctx {
     // tuning (sr_set_option)
     int fit_waves;      // waves per residue in the model-order search: 1, 2 or 4
     int fit_lds;        // 1: stage t, y, 1/sigma of a residue in LDS when it fits; 0: read them from global memory
-    int ct_fft;         // 1: kernel 1 through the FFT formulation when the chunk length allows; 0: always the direct kernel
+    int ct_fft;         // kernel 1 when the chunk length allows: 2 = real-input FFT for 4096 < F + L <= 8192 and complex FFT below
+                        // (default), 1 = complex FFT formulation (k_ct_fft) everywhere, 0 = always the direct kernel
     int fft_table_ready;
     // largest dynamic-LDS size already granted per kernel family (hipFuncSetAttribute is a per-DEVICE setting and a
     // context is bound to one device, so the cache lives here and not in a process-wide static)

@@ -804,6 +804,23 @@ struct RStage1<12> {                                       // n1 = 4 a + b, k1 =
     }
 };
 
+// Hide a value's provenance from the optimiser.  Twiddle bases depend only on the thread, so everything derived from them
+// (11 + 15 + 16 complex powers) is invariant across the six transforms of a series: left alone, the compiler computes them
+// once, parks 100+ registers and spills them (83 scratch stores in the prologue, ~150 reloads per transform; the kernel
+// then waits on scratch 85 % of the time).  Recomputing them per transform is a few dozen multiplies.
+__device__ __forceinline__ cplx opaque(cplx z)
+{
+    asm volatile("" : "+v"(z.re), "+v"(z.im));
+    return z;
+}
+// The same for the thread index: every LDS / global address of the kernel is a function of it, and the ~80 addresses of one
+// transform would otherwise be computed once and spilled.
+__device__ __forceinline__ int opaque(int t)
+{
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 // v[p] *= base^k(p): the powers are built one after the other (k = 1 .. N-1), no table of N powers in registers
 template <int N, class KOF>
 __device__ __forceinline__ void apply_twiddles_seq(cplx *v, cplx base)
@@ -836,7 +853,7 @@ template <int N1>
 __device__ __forceinline__ void rfft_workgroup(cplx *v, cplx *w, cplx *lds, const double *__restrict__ tab, int tid)
 {
     RStage1<N1>::run(v);
-    apply_twiddles_seq<N1, RStage1<N1>>(v, cplx{tab[2 * tid], tab[2 * tid + 1]});
+    apply_twiddles_seq<N1, RStage1<N1>>(v, opaque(cplx{tab[2 * tid], tab[2 * tid + 1]}));
     {
         cplx *b = lds + tid + (tid >> 4);                         // element k1*256 + tid, one pad slot per 16
 #pragma unroll
@@ -851,13 +868,12 @@ __device__ __forceinline__ void rfft_workgroup(cplx *v, cplx *w, cplx *lds, cons
 #pragma unroll
         for (int h = 0; h < 16; ++h) u[h] = b[17 * h];
         fft_reg<4>(u);
-        apply_twiddles_seq<16, RStage1<16>>(u, cplx{tab[2 * (256 + lo)], tab[2 * (256 + lo) + 1]});
-    }
-    __syncthreads();
-    if (act) {
-        cplx *b = lds + 272 * k1 + lo;                            // row (k1*16 + k2a) of 17 slots, column lo
+        apply_twiddles_seq<16, RStage1<16>>(u, opaque(cplx{tab[2 * (256 + lo)], tab[2 * (256 + lo) + 1]}));
+        // in place: element k1*256 + lo + 16 h sits in row (k1*16 + h), column lo -- the very cells this thread has just
+        // read are the ones it writes as row (k1*16 + k2a), column lo: no barrier between its reads and its writes
+        cplx *bw = lds + 272 * k1 + lo;
 #pragma unroll
-        for (int p = 0; p < 16; ++p) b[17 * bitrev<4>(p)] = u[p];
+        for (int p = 0; p < 16; ++p) bw[17 * bitrev<4>(p)] = u[p];
     }
     __syncthreads();
     if (act) {
@@ -871,23 +887,22 @@ __device__ __forceinline__ void rfft_workgroup(cplx *v, cplx *w, cplx *lds, cons
 // HALF: the chunk fills at most 2/3 (N1 = 12) or 1/2 (N1 = 16) of the padded length: the thread's inputs beyond NZ are
 // known to be zero and are neither loaded nor multiplied
 template <int N1, bool HALF>
-__global__ __launch_bounds__(256, N1 == 12 ? 3 : 2) void k_ct_rfft(CtRfftArgs a)
+__global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
 {
     extern __shared__ __align__(16) unsigned char fft_smem[];
     cplx *lds = reinterpret_cast<cplx *>(fft_smem);
     constexpr int H = N1 * 256, M = 2 * H;
     constexpr int NZ = HALF ? (N1 == 12 ? 8 : N1 / 2) : N1;
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     const int v = blockIdx.x / a.R, r = blockIdx.x - v * a.R;
     const int F = a.F;
     const int64_t start = a.chunk_start ? a.chunk_start[r] : (int64_t)r * F;
     const float *px = a.soa + ((int64_t)v * 3 + 0) * a.Npad + start;
-    const int k1 = tid >> 4, k2a = tid & 15;
-    const bool act = k1 < N1;
-    // partner thread holding the frequencies H - k (see the header comment); thread 0 pairs k2b with (16 - k2b) & 15
-    const int pt = k1 != 0 ? (N1 - k1) * 16 + (15 - k2a) : (k2a != 0 ? 16 - k2a : 0);
-    const bool z0 = tid == 0;
-    const cplx wbase = {a.tab[2 * (512 + (act ? k1 + N1 * k2a : 0))], a.tab[2 * (512 + (act ? k1 + N1 * k2a : 0)) + 1]};   // w_M^(k1 + N1 k2a)
+    const bool even = ((start | a.Npad) & 1) == 0;                // frames 2m, 2m + 1 of every plane share an aligned 8 bytes
+    // partner thread holding the frequencies H - k (see the header comment): pt; thread 0 pairs k2b with (16 - k2b) & 15,
+    // everybody else with 15 - k2b: column (15 - k2b + off0) & 15, which only wraps for thread 0 at k2b = 0
+    const cplx wbase = {a.tab[2 * (512 + ((tid0 >> 4) < N1 ? (tid0 >> 4) + N1 * (tid0 & 15) : 0))],
+                        a.tab[2 * (512 + ((tid0 >> 4) < N1 ? (tid0 >> 4) + N1 * (tid0 & 15) : 0)) + 1]};   // w_M^(k1 + N1 k2a)
 
     double W[16], WH = 0.0;
 #pragma unroll
@@ -897,6 +912,11 @@ __global__ __launch_bounds__(256, N1 == 12 ? 3 : 2) void k_ct_rfft(CtRfftArgs a)
     for (int c = 0; c < 6; ++c) {
         // signal c = x^2, y^2, z^2, xy, xz, yz: product of two of the three planes
         asm volatile("" ::: "memory");
+        const int tid = opaque(tid0);
+        const int k1 = tid >> 4, k2a = tid & 15;
+        const bool act = k1 < N1;
+        const int pt = k1 != 0 ? (N1 - k1) * 16 + (15 - k2a) : (k2a != 0 ? 16 - k2a : 0);
+        const int off0 = tid == 0 ? 1 : 0;
         const int ia = c < 3 ? c : (c == 5 ? 1 : 0), ib = c < 3 ? c : (c == 3 ? 1 : 2);
         const float *pa = px + (int64_t)ia * a.Npad, *pb = px + (int64_t)ib * a.Npad;
         float ar[2 * N1], br[2 * N1];
@@ -908,8 +928,17 @@ __global__ __launch_bounds__(256, N1 == 12 ? 3 : 2) void k_ct_rfft(CtRfftArgs a)
             }
             const int f0 = 2 * (tid + 256 * n1), f1 = f0 + 1;
             const bool in0 = f0 < F, in1 = f1 < F;
-            const int c0 = in0 ? f0 : 0, c1 = in1 ? f1 : 0;       // clamped unconditional loads + select (no branch per sample)
-            const float a0 = pa[c0], a1 = pa[c1], b0 = pb[c0], b1 = pb[c1];
+            // clamped unconditional loads + select (no branch per sample); one 8-byte load per plane when the pair is aligned
+            float a0, a1, b0, b1;
+            if (even) {
+                const int c0 = in1 ? f0 : 0;                      // f0 + 1 < F: both frames inside; the last odd frame goes alone
+                const float2 A2 = *reinterpret_cast<const float2 *>(pa + c0), B2 = *reinterpret_cast<const float2 *>(pb + c0);
+                a0 = A2.x; a1 = A2.y; b0 = B2.x; b1 = B2.y;
+                if (in0 && !in1) { a0 = pa[f0]; b0 = pb[f0]; }
+            } else {
+                const int c0 = in0 ? f0 : 0, c1 = in1 ? f1 : 0;
+                a0 = pa[c0]; a1 = pa[c1]; b0 = pb[c0]; b1 = pb[c1];
+            }
             ar[2 * n1] = in0 ? a0 : 0.f; ar[2 * n1 + 1] = in1 ? a1 : 0.f;
             br[2 * n1] = in0 ? b0 : 0.f; br[2 * n1 + 1] = in1 ? b1 : 0.f;
         }
@@ -928,20 +957,20 @@ __global__ __launch_bounds__(256, N1 == 12 ? 3 : 2) void k_ct_rfft(CtRfftArgs a)
         __syncthreads();
         if (act) {
             const double wgt = c < 3 ? 0.25 : 0.5;                // weight / 4
-            const cplx *b = lds + 17 * pt;
+            const cplx *b = lds + 17 * pt + off0;
+            const cplx wb = opaque(wbase);
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                constexpr int dummy = 0; (void)dummy;
                 const int k2b = bitrev<4>(p);
-                const cplx zm = b[z0 ? ((16 - k2b) & 15) : 15 - k2b];
+                const cplx zm = k2b == 0 ? b[15 - 16 * off0] : b[15 - k2b];
                 const cplx zk = w[p];
                 const cplx S = {zk.re + zm.re, zk.im - zm.im}, D = {zk.re - zm.re, zk.im + zm.im};
-                const cplx wk = mul_w32_rt(wbase, k2b);
+                const cplx wk = mul_w32_rt(wb, k2b);
                 const cplx T = cmul(wk, D);
                 const double are = S.re + T.im, aim = S.im - T.re;    // 2 A[k] = S - i w D
                 W[p] = fma(wgt, fma(are, are, aim * aim), W[p]);
             }
-            if (z0) {
+            if (off0) {
                 const double e = w[0].re - w[0].im;                    // A[H] = Re Z[0] - Im Z[0]
                 WH = fma(4.0 * wgt, e * e, WH);
             }
@@ -950,6 +979,11 @@ __global__ __launch_bounds__(256, N1 == 12 ? 3 : 2) void k_ct_rfft(CtRfftArgs a)
     }
 
     // ---- back: Y[k] = (P[k] + P[H-k]) + i (P[k] - P[H-k]) conj(w_M^k), through the same transform ----
+    const int tid = opaque(tid0);
+    const int k1 = tid >> 4, k2a = tid & 15;
+    const bool act = k1 < N1;
+    const int pt = k1 != 0 ? (N1 - k1) * 16 + (15 - k2a) : (k2a != 0 ? 16 - k2a : 0);
+    const int off0 = tid == 0 ? 1 : 0;
     if (act) {
         cplx *b = lds + 17 * tid;
 #pragma unroll
@@ -958,12 +992,12 @@ __global__ __launch_bounds__(256, N1 == 12 ? 3 : 2) void k_ct_rfft(CtRfftArgs a)
     __syncthreads();
     cplx Y[16];
     if (act) {
-        const cplx *b = lds + 17 * pt;
+        const cplx *b = lds + 17 * pt + off0;
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const int k2b = bitrev<4>(p);
-            double Pm = b[z0 ? ((16 - k2b) & 15) : 15 - k2b].re;
-            if (z0 && p == 0) Pm = WH;                                 // k = 0: P[H - 0] = P[H]
+            double Pm = (k2b == 0 ? b[15 - 16 * off0] : b[15 - k2b]).re;
+            if (off0 && p == 0) Pm = WH;                               // k = 0: P[H - 0] = P[H]
             const double E = W[p] + Pm, d = W[p] - Pm;
             const cplx wk = mul_w32_rt(wbase, k2b);                    // (cos, -sin)
             Y[p] = {fma(d, wk.im, E), d * wk.re};                      // E + i d conj(wk) = (E - d sin, d cos), wk.im = -sin

@@ -17,7 +17,7 @@ flight (throughput); `latency_ms` = one batch alone, start to results on the hos
 
 One JSON line is printed by rank 0 (contract in the task statement) with extra objects:
   kernels       one entry per kernel of a step, every `frac` a fraction of a bound THAT kernel can reach, from what it
-                executes:  k_ct_fft -- executed float64 flop / duration against the FP64 vector peak;  k_ct_palmer (the
+                executes:  k_ct_rfft / k_ct_fft -- executed float64 flop / duration against the FP64 vector peak;  k_ct_palmer (the
                 direct formulation, timed alone as a second line) -- 8 flop x exact triples against the FP32 vector peak;
                 k_vechist, k_pack_soa -- algorithmic bytes / duration against the HBM peak;  k_order_search -- residues/s,
                 evaluations/s and the executed float64 flop (PMC count of the committed profile: the data are
@@ -91,7 +91,7 @@ def parse():
     ap.add_argument('--fit-lds', type=int, default=-1, help='1/0: keep residue data in LDS during the fits (-1 = library default)')
     ap.add_argument('--dev-skip-fits', action='store_true', help='DEVELOPMENT ONLY (invalid as a benchmark): leave the fits and the relaxation kernel out, to see the floor the C(t) side alone sets')
     ap.add_argument('--hist-on-main', action='store_true', help='keep the histogram kernel in line with C(t) (only the pack runs beside it)')
-    ap.add_argument('--ct-fft', type=int, default=-1, help='1/0: FFT formulation of the C(t) kernel (-1 = library default)')
+    ap.add_argument('--ct-fft', type=int, default=-1, help='kernel 1: 2 = real-input FFT (k_ct_rfft) where it applies, 1 = complex FFT (k_ct_fft), 0 = direct (k_ct_palmer); -1 = library default (2)')
     ap.add_argument('--depth', type=int, default=6, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true', help='skip the per-kernel alone / saturated timings after the timed region (the `kernels` entries then only carry in-pipeline durations)')
@@ -193,11 +193,17 @@ def cpu_baseline(vecs_host, s, cfg, nv1, nvall):
     return out
 
 
-def fft_exec_flop(s, V):
-    """executed float64 work of k_ct_fft per launch: 4 complex M-point transforms (5 M log2 M flop each), the power
-    spectra of 3 packed pairs (12 flop per frequency each) and the 6 products per frame, per (chunk, vector)."""
+def fft_exec_flop(s, V, real_input=False):
+    """executed float64 work per launch (formula; the committed PMC pass replaces it when it has the kernel).
+    k_ct_fft: 4 complex M-point transforms (5 M log2 M flop each), the power spectra of 3 packed pairs (12 flop per
+    frequency each) and the 6 products per frame, per (chunk, vector).  k_ct_rfft: 7 complex transforms of H = M/2 points,
+    two twiddle passes (6 flop per point) per transform and the real-signal spectrum step (24 flop per frequency) for the
+    six signals."""
     need = s['F'] + s['L']
     M = 2048 if need <= 2048 else (4096 if need <= 4096 else (6144 if need <= 6144 else 8192))
+    if real_input:
+        H = M // 2
+        return M, s['R'] * V * (7 * (5 * H * np.log2(H) + 12 * H) + 6 * 24 * H + 6 * s['F'])
     return M, s['R'] * V * (4 * 5 * M * np.log2(M) + 3 * 12 * M + 6 * s['F'])
 
 
@@ -315,6 +321,8 @@ def main():
     hist_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in events])) if q is not None else None
     fit_ms = None if args.dev_skip_fits else float(np.mean([e[4].elapsed_time(e[5]) for e in events]))
     best = pipe.fit_best
+    nfev_by_order = {str(k): int(np.sum(v)) for k, v in pipe.nfev_last.items()}
+    nfits_by_order = {str(k): int(np.size(v)) for k, v in pipe.nfev_last.items()}
     nfev_step = (pipe.nfev_total - nfev0) / max(1, args.steps)
     depth_used, reserve_used = pipe.depth, pipe.reserve_cus
     listDoG = pipe.listDoG
@@ -361,7 +369,10 @@ def main():
         if 1024 < s['F'] + s['L'] <= 8192 and args.ct_fft != 0:
             ctx.set_option('ct_fft', 0)
             alone['ct_direct'] = timed(lambda: p1.stage_ct(s0, finalize=False), reps=2)
-            ctx.set_option('ct_fft', 1)
+            if args.ct_fft in (-1, 2) and s['F'] + s['L'] > 4096:
+                ctx.set_option('ct_fft', 1)                       # and the complex-FFT formulation it replaced, for reference
+                alone['ct_complex_fft'] = timed(lambda: p1.stage_ct(s0, finalize=False), reps=2)
+            ctx.set_option('ct_fft', 2 if args.ct_fft < 0 else args.ct_fft)
             with torch.cuda.stream(st1):
                 p1.stage_ct(s0)                 # restore the slot's sums / C(t) from the production kernel
         # The model-order search with the chip saturated: 8 batches' residues in ONE launch, the expensive residues first
@@ -399,7 +410,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = triples * world / (elapsed / args.steps)
         use_fft = (args.ct_fft != 0) and 1024 < s['F'] + s['L'] <= 8192
-        kname = 'k_ct_fft' if use_fft else 'k_ct_palmer'
+        use_rfft = use_fft and args.ct_fft in (-1, 2) and s['F'] + s['L'] > 4096
+        kname = 'k_ct_rfft' if use_rfft else ('k_ct_fft' if use_fft else 'k_ct_palmer')
         prof, prof_src = committed_profile() if cfg == 3 and V == 512 else ({}, None)
         N, R, L = s['N'], s['R'], s['L']
         kernels = {}
@@ -429,9 +441,15 @@ def main():
             return e
 
         if use_fft:
-            M, xflop = fft_exec_flop(s, V)
-            entry('k_ct_fft', 'valu-fp64 (float64 vector FMA; latency- and LDS-exchange-limited)', xflop, 1e12, PEAK_FP64_TFLOPS, 'TFLOP/s',
-                  ct_ms, alone.get('ct'), formulation='Wiener-Khinchin: 6 float64 autocorrelations by FFT, whole %d-point transform resident in LDS' % M,
+            M, xflop = fft_exec_flop(s, V, use_rfft)
+            pe = prof_entry(prof, kname)
+            xsrc = 'formula (bench.py:fft_exec_flop)'
+            if pe and pe.get('fp64_flop_per_launch'):
+                xflop, xsrc = pe['fp64_flop_per_launch'], 'PMC float64 instruction counts of the committed profile %s' % prof_src
+            form = ('Wiener-Khinchin on real input: 6 + 1 float64 complex transforms of %d points (half the padded length), two workgroups per CU' % (M // 2)
+                    if use_rfft else 'Wiener-Khinchin: 6 float64 autocorrelations by FFT, whole %d-point transform resident in LDS' % M)
+            entry(kname, 'valu-fp64 (float64 vector FMA; latency- and LDS-exchange-limited)', xflop, 1e12, PEAK_FP64_TFLOPS, 'TFLOP/s',
+                  ct_ms, alone.get('ct'), formulation=form, work_source=xsrc,
                   algorithmic_bytes=12 * N * V + 8 * R * L * V,
                   note='in the pipeline the kernel is confined to %d of %d CUs' % (N_CU - reserve_used, N_CU))
             if alone.get('ct_direct'):
@@ -498,7 +516,8 @@ def main():
             'kernels': kernels,
             'stages_alone_ms': {k: round(v, 4) for k, v in alone.items()},
             'fit': {'residues': V, 'selected_orders': {str(listDoG[j]): int((best == j).sum()) for j in range(len(listDoG))},
-                    'unfitted': int((best < 0).sum()), 'evaluations_per_batch': nfev_step},
+                    'unfitted': int((best < 0).sum()), 'evaluations_per_batch': nfev_step,
+                    'evaluations_by_order': nfev_by_order, 'fits_by_order': nfits_by_order},
             'setup': {'synth_s': gen_s},
             **({'INVALID': 'fits skipped (--dev-skip-fits)'} if args.dev_skip_fits else {}),
         }

@@ -225,7 +225,7 @@ def test_bench_json_contract():
         assert k in r, k
     # every fraction is a fraction of a bound its kernel can reach: in (0, 1]
     ks = j['kernels']
-    assert r['kernel'] in ks and set(ks) >= {'k_ct_fft', 'k_ct_palmer', 'k_vechist', 'k_pack_soa', 'k_order_search'}
+    assert r['kernel'] in ks and set(ks) >= {'k_ct_rfft', 'k_ct_palmer', 'k_vechist', 'k_pack_soa', 'k_order_search'}
     top = ks[r['kernel']]
     assert top['cu_ms_per_batch'] == max(v['cu_ms_per_batch'] for k, v in ks.items() if k != 'k_ct_palmer')
     for name, e in ks.items():
@@ -234,10 +234,10 @@ def test_bench_json_contract():
                 assert 0 < e[f] <= 1.0, (name, f, e[f])
     if r['frac'] is not None:
         assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0 < r['frac'] <= 1
-    ct = ks['k_ct_fft']
+    ct = ks['k_ct_rfft']
     assert 0 < ct['in_pipeline_ms'] < j['ms_per_step'] * 1.05 and ct['alone_ms'] <= ct['in_pipeline_ms'] * 1.05
     assert abs(ct['frac'] - ct['work_per_launch'] / (ct['in_pipeline_ms'] * 1e-3) / 1e12 / ct['peak']) < 1e-9
-    assert ct['work_per_launch'] < 0.1 * 8 * j['config']['exact_triples_per_gpu']          # the FFT executes < 10 % of the direct flop
+    assert ct['work_per_launch'] < 0.1 * 8 * j['config']['exact_triples_per_gpu']          # the FFT formulation executes < 10 % of the direct flop
     vh = ks['k_vechist']
     assert vh['bound'] == 'hbm' and abs(vh['achieved'] - vh['work_per_launch'] / (vh['in_pipeline_ms'] * 1e-3) / 1e9) < 1e-6 * vh['achieved']
     fit = ks['k_order_search']

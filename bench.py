@@ -85,7 +85,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', type=str, default='cfg3', choices=['cfg2', 'cfg3'])
     ap.add_argument('--vectors', type=int, default=None, help='vectors per GPU (default: the config value)')
-    ap.add_argument('--reserve-cus', type=int, default=128, help='CUs kept free of the C(t)/histogram kernels for the latency-bound fit kernels (CU-masked stream; 0 = no partition)')
+    ap.add_argument('--reserve-cus', type=int, default=0, help='CUs kept free of the C(t)/histogram kernels for the latency-bound fit kernels (CU-masked stream; 0 = no partition)')
     ap.add_argument('--fits-on-reserved-only', type=int, default=1, help='1/0: confine the fit kernels to the reserved CUs (strict partition)')
     ap.add_argument('--fit-waves', type=int, default=0, help='wavefronts per residue in the model-order search (0 = library default)')
     ap.add_argument('--fit-lds', type=int, default=-1, help='1/0: keep residue data in LDS during the fits (-1 = library default)')

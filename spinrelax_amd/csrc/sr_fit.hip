@@ -1144,8 +1144,8 @@ int launch_search(sr_ctx *ctx, const SearchArgs &a)
 {
     switch (ctx->fit_waves) {
         case 1: return launch_search_w<NMAX, 1>(ctx, a);
-        case 2: return launch_search_w<NMAX, 2>(ctx, a);
-        default: return launch_search_w<NMAX, 4>(ctx, a);
+        case 4: return launch_search_w<NMAX, 4>(ctx, a);
+        default: return launch_search_w<NMAX, 2>(ctx, a);
     }
 }
 
@@ -1183,12 +1183,9 @@ __global__ __launch_bounds__(256) void k_resjac(const double *__restrict__ t, co
     }
 }
 
-template <int N>
-int launch_trf(sr_ctx *ctx, const FitArgs &a)
+template <int N, int W>
+int launch_trf_w(sr_ctx *ctx, const FitArgs &a)
 {
-    // 4 waves = one per SIMD of a CU: the redundant serial algebra is VALU-issue bound, a second wave per
-    // SIMD doubles its time (measured at n = 9: 68 / 41 / 28 / 51 us per iteration for W = 1 / 2 / 4 / 8)
-    constexpr int W = 4;
     const size_t lds_small = fit_lds_doubles(W, 0) * sizeof(double);
     const size_t lds_full = fit_lds_doubles(W, a.L) * sizeof(double);
     if (lds_full <= sr_lds_limit(ctx)) {
@@ -1201,6 +1198,19 @@ int launch_trf(sr_ctx *ctx, const FitArgs &a)
     }
     SR_HIP(hipGetLastError());
     return 0;
+}
+
+// The single-order solver uses the same number of waves per residue as the model-order search (sr_set_option
+// "fit_waves"): the workgroup sums are combined wave by wave, so only equal wave counts give bit-identical fits --
+// which is what lets the host-driven search (one sr_expfit_lm_f64 call per order) reproduce the one-launch search exactly.
+template <int N>
+int launch_trf(sr_ctx *ctx, const FitArgs &a)
+{
+    switch (ctx->fit_waves) {
+        case 1: return launch_trf_w<N, 1>(ctx, a);
+        case 4: return launch_trf_w<N, 4>(ctx, a);
+        default: return launch_trf_w<N, 2>(ctx, a);
+    }
 }
 
 int dispatch_trf(sr_ctx *ctx, int P, const FitArgs &a)
@@ -1267,7 +1277,7 @@ int sr_expfit_order_search_f64_dev(sr_ctx *ctx, const double *t, const double *C
         pmax = orders[j] > pmax ? orders[j] : pmax;
     }
     for (int j = nOrders; j < kMaxOrders; ++j) { a.orders[j] = 0; a.tau_off[j] = 0; }
-    const size_t lds_full = fit_lds_doubles(4, L) * sizeof(double);
+    const size_t lds_full = fit_lds_doubles(ctx->fit_waves, L) * sizeof(double);
     double *fws = work;
     if (!fws && (!ctx->fit_lds || lds_full > sr_lds_limit(ctx))) {
         fws = (double *)sr_workspace(ctx, SR_WS_FIT, (size_t)nRes * L * sizeof(double));

@@ -835,6 +835,22 @@ __device__ __forceinline__ void apply_twiddles_seq(cplx *v, cplx base)
     }
 }
 
+// v[p] *= base^k(p) with the powers built as a tree (base^k = base^(k/2) * base^(k - k/2)): dependency depth log2 N
+// instead of N (the sequential chain cost 12 % of the kernel: every wave waits on it at one or two waves per SIMD)
+template <int N, class KOF>
+__device__ __forceinline__ void apply_twiddles_tree(cplx *v, cplx base)
+{
+    cplx pw[N];
+    pw[1] = base;
+#pragma unroll
+    for (int k = 2; k < N; ++k) pw[k] = cmul(pw[k >> 1], pw[k - (k >> 1)]);
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+        const int k = KOF::k1(p);
+        if (k != 0) v[p] = cmul(v[p], pw[k]);
+    }
+}
+
 struct CtRfftArgs {
     const float *soa;
     int64_t Npad;
@@ -850,10 +866,10 @@ __host__ __device__ constexpr int rfft_lds_slots(int N1) { return 256 * N1 + 256
 // (k1, k2a) = (tid >> 4, tid & 15), k1 < N1: w[p] = X[k1 + N1 (k2a + 16 rev4(p))].  The caller has made sure nobody still
 // reads the LDS image; on return every thread has read what it needs from it (row tid is the thread's own).
 template <int N1>
-__device__ __forceinline__ void rfft_workgroup(cplx *v, cplx *w, cplx *lds, const double *__restrict__ tab, int tid)
+__device__ __forceinline__ void rfft_workgroup(cplx *v, cplx *w, cplx *lds, cplx base1, int tid)
 {
     RStage1<N1>::run(v);
-    apply_twiddles_seq<N1, RStage1<N1>>(v, opaque(cplx{tab[2 * tid], tab[2 * tid + 1]}));
+    apply_twiddles_tree<N1, RStage1<N1>>(v, base1);
     {
         cplx *b = lds + tid + (tid >> 4);                         // element k1*256 + tid, one pad slot per 16
 #pragma unroll
@@ -868,7 +884,11 @@ __device__ __forceinline__ void rfft_workgroup(cplx *v, cplx *w, cplx *lds, cons
 #pragma unroll
         for (int h = 0; h < 16; ++h) u[h] = b[17 * h];
         fft_reg<4>(u);
-        apply_twiddles_seq<16, RStage1<16>>(u, opaque(cplx{tab[2 * (256 + lo)], tab[2 * (256 + lo) + 1]}));
+        {
+            const cplx *tw = lds + rfft_lds_slots(N1) + lo;       // w_256^(lo k2a) at [k2a*16 + lo], filled at kernel start
+#pragma unroll
+            for (int p = 1; p < 16; ++p) u[p] = cmul(u[p], tw[16 * bitrev<4>(p)]);
+        }
         // in place: element k1*256 + lo + 16 h sits in row (k1*16 + h), column lo -- the very cells this thread has just
         // read are the ones it writes as row (k1*16 + k2a), column lo: no barrier between its reads and its writes
         cplx *bw = lds + 272 * k1 + lo;
@@ -898,57 +918,79 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
     const int F = a.F;
     const int64_t start = a.chunk_start ? a.chunk_start[r] : (int64_t)r * F;
     const float *px = a.soa + ((int64_t)v * 3 + 0) * a.Npad + start;
-    const bool even = ((start | a.Npad) & 1) == 0;                // frames 2m, 2m + 1 of every plane share an aligned 8 bytes
+    const bool even = ((start | a.Npad | (int64_t)F) & 1) == 0;   // frames 2m, 2m + 1 of every plane share an aligned 8 bytes,
+                                                                  // and no pair straddles the end of the chunk
     // partner thread holding the frequencies H - k (see the header comment): pt; thread 0 pairs k2b with (16 - k2b) & 15,
     // everybody else with 15 - k2b: column (15 - k2b + off0) & 15, which only wraps for thread 0 at k2b = 0
     const cplx wbase = {a.tab[2 * (512 + ((tid0 >> 4) < N1 ? (tid0 >> 4) + N1 * (tid0 & 15) : 0))],
                         a.tab[2 * (512 + ((tid0 >> 4) < N1 ? (tid0 >> 4) + N1 * (tid0 & 15) : 0)) + 1]};   // w_M^(k1 + N1 k2a)
 
-    double W[16], WH = 0.0;
+    // Power spectrum, by PAIRS of frequencies (k, H - k): thread (k1, k2a) owns the pairs whose k has k2b < 8; it keeps
+    // Wk[q] = P[k] (k2b = q) and Wm[q] = P[H - k] (the partner thread's frequency 15 - q).  With S = Z[k] + conj Z[H-k],
+    // D = Z[k] - conj Z[H-k], T = w_M^k D:   4 |A[k]|^2 = |S - i T|^2   and   4 |A[H-k]|^2 = |S + i T|^2  -- one complex
+    // multiply serves both.  Thread 0 is its own partner with k2b <-> 16 - k2b: its slot q = 0 holds k = 0 (Wk) and k = H
+    // (Wm), and the self-paired frequency k = H/2 (k2b = 8) gets the scalar Wmid.
+    double Wk[8], Wm[8], Wmid = 0.0;
 #pragma unroll
-    for (int p = 0; p < 16; ++p) W[p] = 0.0;
+    for (int q = 0; q < 8; ++q) Wk[q] = Wm[q] = 0.0;
+    {
+        // step-2 twiddles w_256^(lo k2a), transposed so that the 16 lanes of a ds_read_b128 group (consecutive lo) hit 16
+        // consecutive slots; ordered before their first use by the first barrier of the first transform
+        const int j = ((tid0 & 15) * (tid0 >> 4)) & 255;
+        lds[rfft_lds_slots(N1) + tid0] = cplx{a.tab[2 * (256 + j)], a.tab[2 * (256 + j) + 1]};
+    }
 
+    // signal c = x^2, y^2, z^2, xy, xz, yz: product of two of the three planes.  Thread t holds the pairs of frames
+    // (2m, 2m + 1), m = t + 256 n1; clamped unconditional loads + select (no branch per sample), one 8-byte load per plane
+    // when the pair is aligned.  The loads of signal c + 1 are issued before the transform of signal c (15 % of the
+    // kernel was spent waiting for them at the top of every transform).
+    float2 ar[NZ], br[NZ];           // raw loads; frames past the chunk are masked where the values are consumed
+#define SR_RFFT_LOAD(C, T)                                                                       \
+    {                                                                                            \
+        const int cc_ = (C);                                                                     \
+        const int ia_ = cc_ < 3 ? cc_ : (cc_ == 5 ? 1 : 0), ib_ = cc_ < 3 ? cc_ : (cc_ == 3 ? 1 : 2); \
+        const float *pa_ = px + (int64_t)ia_ * a.Npad, *pb_ = px + (int64_t)ib_ * a.Npad;        \
+        _Pragma("unroll") for (int n1 = 0; n1 < NZ; ++n1) {                                      \
+            const int f0 = 2 * ((T) + 256 * n1), f1 = f0 + 1;                                    \
+            if (even) {                                                                          \
+                const int c0 = f1 < F ? f0 : 0;                                                  \
+                ar[n1] = *reinterpret_cast<const float2 *>(pa_ + c0);                            \
+                br[n1] = *reinterpret_cast<const float2 *>(pb_ + c0);                            \
+            } else {                                                                             \
+                const int c0 = f0 < F ? f0 : 0, c1 = f1 < F ? f1 : 0;                            \
+                ar[n1] = make_float2(pa_[c0], pa_[c1]);                                          \
+                br[n1] = make_float2(pb_[c0], pb_[c1]);                                          \
+            }                                                                                    \
+        }                                                                                        \
+    }
+    SR_RFFT_LOAD(0, tid0)
 #pragma unroll 1
     for (int c = 0; c < 6; ++c) {
-        // signal c = x^2, y^2, z^2, xy, xz, yz: product of two of the three planes
         asm volatile("" ::: "memory");
         const int tid = opaque(tid0);
         const int k1 = tid >> 4, k2a = tid & 15;
         const bool act = k1 < N1;
         const int pt = k1 != 0 ? (N1 - k1) * 16 + (15 - k2a) : (k2a != 0 ? 16 - k2a : 0);
         const int off0 = tid == 0 ? 1 : 0;
-        const int ia = c < 3 ? c : (c == 5 ? 1 : 0), ib = c < 3 ? c : (c == 3 ? 1 : 2);
-        const float *pa = px + (int64_t)ia * a.Npad, *pb = px + (int64_t)ib * a.Npad;
-        float ar[2 * N1], br[2 * N1];
+        // the samples of this signal were loaded while the previous transform ran (before the loop for the first one)
+        cplx sig[N1];
 #pragma unroll
         for (int n1 = 0; n1 < N1; ++n1) {
             if (n1 >= NZ) {
-                ar[2 * n1] = ar[2 * n1 + 1] = br[2 * n1] = br[2 * n1 + 1] = 0.f;
+                sig[n1] = cplx{0.0, 0.0};
                 continue;
             }
-            const int f0 = 2 * (tid + 256 * n1), f1 = f0 + 1;
-            const bool in0 = f0 < F, in1 = f1 < F;
-            // clamped unconditional loads + select (no branch per sample); one 8-byte load per plane when the pair is aligned
-            float a0, a1, b0, b1;
-            if (even) {
-                const int c0 = in1 ? f0 : 0;                      // f0 + 1 < F: both frames inside; the last odd frame goes alone
-                const float2 A2 = *reinterpret_cast<const float2 *>(pa + c0), B2 = *reinterpret_cast<const float2 *>(pb + c0);
-                a0 = A2.x; a1 = A2.y; b0 = B2.x; b1 = B2.y;
-                if (in0 && !in1) { a0 = pa[f0]; b0 = pb[f0]; }
-            } else {
-                const int c0 = in0 ? f0 : 0, c1 = in1 ? f1 : 0;
-                a0 = pa[c0]; a1 = pa[c1]; b0 = pb[c0]; b1 = pb[c1];
-            }
-            ar[2 * n1] = in0 ? a0 : 0.f; ar[2 * n1 + 1] = in1 ? a1 : 0.f;
-            br[2 * n1] = in0 ? b0 : 0.f; br[2 * n1 + 1] = in1 ? b1 : 0.f;
+            const int f0 = 2 * (tid + 256 * n1);
+            const double p0 = (double)ar[n1].x * (double)br[n1].x, p1 = (double)ar[n1].y * (double)br[n1].y;
+            sig[n1] = cplx{f0 < F ? p0 : 0.0, f0 + 1 < F ? p1 : 0.0};
         }
-        cplx sig[N1];
-#pragma unroll
-        for (int n1 = 0; n1 < N1; ++n1)
-            sig[n1] = {(double)ar[2 * n1] * (double)br[2 * n1], (double)ar[2 * n1 + 1] * (double)br[2 * n1 + 1]};
+        // step-1 twiddle base w_H^tid: loaded BEFORE the prefetch so that waiting for it (vmcnt counts in order) leaves the
+        // prefetched samples in flight
+        const cplx base1 = opaque(cplx{a.tab[2 * tid], a.tab[2 * tid + 1]});
+        if (c < 5) SR_RFFT_LOAD(c + 1, tid)
         cplx w[16];
-        rfft_workgroup<N1>(sig, w, lds, a.tab, tid);
-        // own row again, now in frequency order k2b; then every thread reads the partner frequencies
+        rfft_workgroup<N1>(sig, w, lds, base1, tid);
+        // own row again, now in frequency order k2b; then every thread reads the partner frequencies of its 8 pairs
         if (act) {
             cplx *b = lds + 17 * tid;
 #pragma unroll
@@ -960,55 +1002,53 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
             const cplx *b = lds + 17 * pt + off0;
             const cplx wb = opaque(wbase);
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const int k2b = bitrev<4>(p);
-                const cplx zm = k2b == 0 ? b[15 - 16 * off0] : b[15 - k2b];
-                const cplx zk = w[p];
+            for (int q = 0; q < 8; ++q) {
+                const cplx zk = w[bitrev<4>(q)];
+                if (q == 0 && off0) {                              // thread 0: k = 0 and k = H from Z[0] alone
+                    const double e0 = zk.re + zk.im, eh = zk.re - zk.im;
+                    Wk[0] = fma(4.0 * wgt, e0 * e0, Wk[0]);
+                    Wm[0] = fma(4.0 * wgt, eh * eh, Wm[0]);
+                    continue;
+                }
+                const cplx zm = b[15 - q];
                 const cplx S = {zk.re + zm.re, zk.im - zm.im}, D = {zk.re - zm.re, zk.im + zm.im};
-                const cplx wk = mul_w32_rt(wb, k2b);
-                const cplx T = cmul(wk, D);
-                const double are = S.re + T.im, aim = S.im - T.re;    // 2 A[k] = S - i w D
-                W[p] = fma(wgt, fma(are, are, aim * aim), W[p]);
+                const cplx T = cmul(mul_w32_rt(wb, q), D);
+                const double pr = S.re + T.im, pi = S.im - T.re;      // S - i T
+                const double mr = S.re - T.im, mi = S.im + T.re;      // S + i T
+                Wk[q] = fma(wgt, fma(pr, pr, pi * pi), Wk[q]);
+                Wm[q] = fma(wgt, fma(mr, mr, mi * mi), Wm[q]);
             }
-            if (off0) {
-                const double e = w[0].re - w[0].im;                    // A[H] = Re Z[0] - Im Z[0]
-                WH = fma(4.0 * wgt, e * e, WH);
+            if (off0) {                                            // k = H/2 (k2b = 8) mirrors onto itself
+                const cplx zk = w[bitrev<4>(8)];
+                const cplx S = {2.0 * zk.re, 0.0}, D = {0.0, 2.0 * zk.im};
+                const cplx T = cmul(mul_w32_rt(wb, 8), D);
+                const double pr = S.re + T.im, pi = S.im - T.re;
+                Wmid = fma(wgt, fma(pr, pr, pi * pi), Wmid);
             }
         }
         __syncthreads();
     }
 
-    // ---- back: Y[k] = (P[k] + P[H-k]) + i (P[k] - P[H-k]) conj(w_M^k), through the same transform ----
+    // ---- back: Y[k] = (P[k] + P[H-k]) + i (P[k] - P[H-k]) conj(w_M^k), through the same transform.  The pair owner has
+    // both P[k] and P[H-k]:  Y[k] = (E - d sin, d cos),  Y[H-k] = (E + d sin, d cos)  with E = P[k] + P[H-k],
+    // d = P[k] - P[H-k], w_M^k = (cos, -sin).  Natural order with one pad slot per N1 elements: k + k2a + 16 k2b. ----
     const int tid = opaque(tid0);
     const int k1 = tid >> 4, k2a = tid & 15;
     const bool act = k1 < N1;
     const int pt = k1 != 0 ? (N1 - k1) * 16 + (15 - k2a) : (k2a != 0 ? 16 - k2a : 0);
     const int off0 = tid == 0 ? 1 : 0;
     if (act) {
-        cplx *b = lds + 17 * tid;
+        cplx *bk = lds + k1 + (N1 + 1) * k2a;                                    // own frequencies, column k2b = q
+        cplx *bm = lds + (pt >> 4) + (N1 + 1) * (pt & 15) + 16 * (N1 + 1) * off0;  // the partner's, column 15 - q (+ 1 for thread 0)
+        const cplx wb = opaque(wbase);
 #pragma unroll
-        for (int p = 0; p < 16; ++p) b[bitrev<4>(p)] = {W[p], 0.0};
-    }
-    __syncthreads();
-    cplx Y[16];
-    if (act) {
-        const cplx *b = lds + 17 * pt + off0;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int k2b = bitrev<4>(p);
-            double Pm = (k2b == 0 ? b[15 - 16 * off0] : b[15 - k2b]).re;
-            if (off0 && p == 0) Pm = WH;                               // k = 0: P[H - 0] = P[H]
-            const double E = W[p] + Pm, d = W[p] - Pm;
-            const cplx wk = mul_w32_rt(wbase, k2b);                    // (cos, -sin)
-            Y[p] = {fma(d, wk.im, E), d * wk.re};                      // E + i d conj(wk) = (E - d sin, d cos), wk.im = -sin
+        for (int q = 0; q < 8; ++q) {
+            const double E = Wk[q] + Wm[q], d = Wk[q] - Wm[q];
+            const cplx wk = mul_w32_rt(wb, q);                                  // (cos, -sin)
+            bk[16 * (N1 + 1) * q] = {fma(d, wk.im, E), d * wk.re};
+            if (!(q == 0 && off0)) bm[16 * (N1 + 1) * (15 - q)] = {fma(-d, wk.im, E), d * wk.re};
         }
-    }
-    __syncthreads();
-    if (act) {
-        // natural order k = k1 + N1 (k2a + 16 k2b), one pad slot per N1 elements: k + k2a + 16 k2b
-        cplx *b = lds + k1 + (N1 + 1) * k2a;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) b[16 * (N1 + 1) * bitrev<4>(p)] = Y[p];
+        if (off0) bk[16 * (N1 + 1) * 8] = {2.0 * Wmid, 0.0};                     // k = H/2: E = 2 P, d = 0
     }
     __syncthreads();
     {
@@ -1020,7 +1060,7 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
         }
         __syncthreads();
         cplx w[16];
-        rfft_workgroup<N1>(sig, w, lds, a.tab, tid);
+        rfft_workgroup<N1>(sig, w, lds, opaque(cplx{a.tab[2 * tid], a.tab[2 * tid + 1]}), tid);
         if (act) {
             double *out = a.psum + ((int64_t)v * a.R + r) * a.Lp;
             const double inv = 1.0 / (double)M;
@@ -1038,7 +1078,7 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
 template <int N1, bool HALF>
 int launch_ct_rfft_h(sr_ctx *ctx, const CtRfftArgs &a, int64_t series)
 {
-    const size_t lds = (size_t)rfft_lds_slots(N1) * sizeof(cplx);
+    const size_t lds = (size_t)(rfft_lds_slots(N1) + 256) * sizeof(cplx);      // transform image + the 16 x 16 step-2 twiddles
     if (lds > 64 * 1024)
         SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ct_rfft<N1, HALF>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -242,6 +242,24 @@ int sr_jomega_relax_f64_dev(sr_ctx *, int model, const double *D, int E, const d
                             const int *nComps, int B, const double *binvecs, const double *weights, int noe_mode,
                             double *out, double *Jout, double *stats);
 
+/* Residue-specific CSA search of the new class API: replaces the per-residue fmin_powell loop of
+ * spinRelaxationExperiments.optimisation_loop_do_local_step / optimisation_loop_do_local_step's objective
+ * (spectral_densities.py:1371-1382, 1430-1447).  One device thread per residue runs scipy's one-variable Powell / Brent
+ * search (restated from scipy/optimize/_optimize.py, see sr_relax.hip) over the closed forms the 12 statistics of
+ * sr_jomega_relax_f64 give:
+ *   stats (E, nRes, 12); column[e] = 0 R1, 1 R2, 2 NOE; csa_prefactor[e]: f_CSA = csa^2 * csa_prefactor[e];
+ *   noe_factor[e] = time_fact * gamma_B / gamma_A, f_DD[e]; target / dtarget (E, nRes): the measured value and its
+ *   uncertainty (0 when the file has none) of residue i in experiment e, read only where cover[e, i] != 0;
+ *   has_err: the model values carry a sigma (vector distribution given); csa0 (nRes) start values; step = the initial
+ *   direction (dictStepSizes['rsCSA']); xtol, ftol as fmin_powell's (1e-4 both in the reference's call).
+ * Outputs: csa (nRes) = the LAST evaluated CSA of each search (what the reference keeps), values / errors (E, nRes) at
+ * that CSA for covered entries (0 elsewhere), fopt (nRes) Powell's final objective, nfev (nRes) objective calls.
+ * Residues no experiment covers keep csa0 and nfev = 0.  Host pointers. */
+int sr_rscsa_search_f64(sr_ctx *, int E, int nRes, const double *stats, const int *column, const double *csa_prefactor,
+                        const double *noe_factor, const double *f_DD, const double *target, const double *dtarget,
+                        const unsigned char *cover, int has_err, const double *csa0, double step, double xtol, double ftol,
+                        double *csa, double *values, double *errors, double *fopt, int *nfev);
+
 /* ---- trajectory front end ----------------------------------------
  * Replaces obtain_XHvecs (calculate-Ct-from-traj.py:64-86) with vecnorm_NDarray (transforms3d_supplement.py:40-52) and the
  * MDTraj center_coordinates + superpose(ref, frame=0, atom_indices=fit_indices) step between its two calls (:466-467):

@@ -2,7 +2,7 @@
 """Developer diagnostic: error of the GPU C(t) vs the golden float64 reference values."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from spinrelax_amd import synth
 from spinrelax_amd.hip import Context

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from spinrelax_amd import synth                      # noqa: E402
 from spinrelax_amd.hip import Context                # noqa: E402
 from spinrelax_amd.pipeline import DevicePipeline    # noqa: E402

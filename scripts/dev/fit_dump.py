@@ -2,7 +2,7 @@
 """Developer diagnostic: run the device fit on every golden trial and dump the results."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from spinrelax_amd.hip import Context
 ctx = Context(0)

@@ -2,7 +2,7 @@
 """Developer diagnostic: does an idle gap before the C(t) kernel change its duration (clock ramp)?"""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from spinrelax_amd import synth
 from spinrelax_amd.hip import Context
 s = synth.config_shapes(3); V = 512

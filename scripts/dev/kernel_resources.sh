@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool: register / scratch / occupancy table of every kernel in one source file.
-# usage: scripts/dev_kernel_resources.sh spinrelax_amd/csrc/sr_fit.hip [extra hipcc flags]
+# usage: scripts/dev/kernel_resources.sh spinrelax_amd/csrc/sr_fit.hip [extra hipcc flags]
 src=$1; shift
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -c "$src" -o /tmp/_res_tmp.o \
     -Rpass-analysis=kernel-resource-usage "$@" 2>&1 | python3 -c "

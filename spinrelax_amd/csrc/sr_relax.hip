@@ -217,6 +217,262 @@ T *upload(sr_ctx *ctx, int slot, const T *host, size_t count, int *rc)
     return d;
 }
 
+
+// ---- residue-specific CSA search (new class API) -------------------------------------------------------------------
+// spectral_densities.py:1371-1382 + 1430-1447: for every residue, fmin_powell over ONE variable (its CSA) of the
+// mean of (value - target)^2 / (sigma_value^2 + sigma_target^2) over the experiments that cover the residue.  With
+// the 12 sufficient statistics k_relax already produces, value and sigma are closed forms of csa^2, so a whole search
+// is a few dozen evaluations of ~20 float64 operations per experiment: one thread per residue runs it start to end.
+// The optimiser is scipy's (unpinned in requirements.txt; 1.15.3 in the build container), restated for N = 1:
+//   _minimize_powell        scipy/optimize/_optimize.py:3375-3585   (xtol = ftol = 1e-4, maxiter = maxfev = 1000)
+//   _linesearch_powell      :3176-3222  -> Brent without bounds, tol = 100 xtol
+//   bracket                 :2916-3073  (xa = 0, xb = 1, grow_limit = 110), _recover_from_bracket_error :3079-3110
+//   Brent.optimize          :2463-2572
+// Every expression keeps Python's operation order and is compiled without contraction, so the search walks the
+// same path as the host loop it replaces and ends on the same last-evaluated CSA (the value the reference keeps:
+// it ignores fmin_powell's return value and relies on the objective's side effect).
+struct RscsaArgs {
+    int E, n, has_err, maxfun, maxiter;
+    double step, xtol, ftol;
+    const double *stats;          // (E, n, 12)
+    const int *col;               // (E) 0 = R1, 1 = R2, 2 = NOE
+    const double *pref;           // (E) f_CSA = csa^2 * pref
+    const double *cnoe;           // (E) time_fact * gamma_B / gamma_A
+    const double *fdd;            // (E)
+    const double *y, *dy;         // (E, n) targets and their uncertainties (0 where there is none)
+    const unsigned char *cover;   // (E, n)
+    const double *csa0;           // (n)
+    double *csa, *val, *err, *fopt;   // (n), (E, n), (E, n), (n)
+    int *nfev;                    // (n)
+};
+
+struct RscsaObjective {
+    const RscsaArgs &a;
+    int i, ncover, calls;
+    bool stop;                    // _MaxFuncCallError raised: unwind to _minimize_powell's loop
+    double last;
+
+    __device__ void closed_form(int e, double csa, double &v, double &dv) const
+    {
+#pragma clang fp contract(off)
+        const double *st = a.stats + ((size_t)e * a.n + i) * 12;
+        const double f = csa * csa * a.pref[e];
+        double var;
+        if (a.col[e] == 0) {
+            v = st[0] + f * st[1];
+            var = st[2] + 2.0 * f * st[3] + f * f * st[4];
+        } else if (a.col[e] == 1) {
+            v = st[5] + f * st[6];
+            var = st[7] + 2.0 * f * st[8] + f * f * st[9];
+        } else {
+            const double R1 = st[0] + f * st[1];
+            const double c = a.cnoe[e] / R1 * a.fdd[e];
+            v = 1.0 + c * st[10];
+            var = c * c * st[11];
+        }
+        dv = a.has_err ? sqrt(0.0 > var ? 0.0 : var) : 0.0;
+    }
+
+    __device__ double operator()(double csa)
+    {
+#pragma clang fp contract(off)
+        if (calls >= a.maxfun) { stop = true; return NAN; }
+        calls += 1;
+        last = csa;
+        double chisq = 0.0;
+        for (int e = 0; e < a.E; ++e) {
+            if (!a.cover[(size_t)e * a.n + i]) continue;
+            double v, dv;
+            closed_form(e, csa, v, dv);
+            const double dt = a.dy[(size_t)e * a.n + i];
+            double w = dv * dv + dt * dt;
+            if (w == 0) w = 1.0;
+            const double r = v - a.y[(size_t)e * a.n + i];
+            chisq += r * r / w;
+        }
+        return chisq / (double)ncover;
+    }
+};
+
+// min over alpha of f(p + alpha*xi); returns alpha_min and the value there (Brent on bracket(0, 1)).
+__device__ void rscsa_line_min(RscsaObjective &f, double p, double xi, double tol, double &alpha_min, double &fret)
+{
+#pragma clang fp contract(off)
+    auto g = [&](double alpha) { return f(p + alpha * xi); };
+    // ---- bracket ----
+    const double gold = 1.618034, verysmall = 1e-21, grow_limit = 110.0;
+    double xa = 0.0, xb = 1.0;
+    double fa = g(xa); if (f.stop) return;
+    double fb = g(xb); if (f.stop) return;
+    if (fa < fb) { double t = xa; xa = xb; xb = t; t = fa; fa = fb; fb = t; }
+    double xc = xb + gold * (xb - xa);
+    double fc = g(xc); if (f.stop) return;
+    int it = 0;
+    while (fc < fb) {
+        const double tmp1 = (xb - xa) * (fb - fc);
+        const double tmp2 = (xb - xc) * (fb - fa);
+        const double val = tmp2 - tmp1;
+        const double denom = fabs(val) < verysmall ? 2.0 * verysmall : 2.0 * val;
+        double w = xb - ((xb - xc) * tmp2 - (xb - xa) * tmp1) / denom;
+        const double wlim = xb + grow_limit * (xc - xb);
+        if (it > 1000) { f.stop = true; return; }       // scipy raises RuntimeError here
+        it += 1;
+        double fw;
+        if ((w - xc) * (xb - w) > 0.0) {
+            fw = g(w); if (f.stop) return;
+            if (fw < fc) { xa = xb; xb = w; fa = fb; fb = fw; break; }
+            else if (fw > fb) { xc = w; fc = fw; break; }
+            w = xc + gold * (xc - xb);
+            fw = g(w); if (f.stop) return;
+        } else if ((w - wlim) * (wlim - xc) >= 0.0) {
+            w = wlim;
+            fw = g(w); if (f.stop) return;
+        } else if ((w - wlim) * (xc - w) > 0.0) {
+            fw = g(w); if (f.stop) return;
+            if (fw < fc) {
+                xb = xc; xc = w; w = xc + gold * (xc - xb);
+                fb = fc; fc = fw;
+                fw = g(w); if (f.stop) return;
+            }
+        } else {
+            w = xc + gold * (xc - xb);
+            fw = g(w); if (f.stop) return;
+        }
+        xa = xb; xb = xc; xc = w;
+        fa = fb; fb = fc; fc = fw;
+    }
+    const bool cond1 = (fb < fc && fb <= fa) || (fb < fa && fb <= fc);
+    const bool cond2 = (xa < xb && xb < xc) || (xc < xb && xb < xa);
+    const bool cond3 = isfinite(xa) && isfinite(xb) && isfinite(xc);
+    if (!(cond1 && cond2 && cond3)) {
+        // _recover_from_bracket_error: the best of the three points (numpy.argmin: first minimum, NaN wins)
+        if (isnan(xa) || isnan(xb) || isnan(xc) || isnan(fa) || isnan(fb) || isnan(fc)) { alpha_min = NAN; fret = NAN; return; }
+        alpha_min = xa; fret = fa;
+        if (fb < fret) { alpha_min = xb; fret = fb; }
+        if (fc < fret) { alpha_min = xc; fret = fc; }
+        return;
+    }
+    // ---- Brent ----
+    const double mintol = 1.0e-11, cg = 0.3819660;
+    double x = xb, w = xb, v = xb, fx = fb, fw = fb, fv = fb;
+    double lo = xa < xc ? xa : xc, hi = xa < xc ? xc : xa;
+    double deltax = 0.0, rat = 0.0;
+    for (int iter = 0; iter < 500; ++iter) {
+        const double tol1 = tol * fabs(x) + mintol;
+        const double tol2 = 2.0 * tol1;
+        const double xmid = 0.5 * (lo + hi);
+        if (fabs(x - xmid) < (tol2 - 0.5 * (hi - lo))) break;
+        if (fabs(deltax) <= tol1) {
+            deltax = (x >= xmid) ? lo - x : hi - x;
+            rat = cg * deltax;
+        } else {
+            double tmp1 = (x - w) * (fx - fv);
+            double tmp2 = (x - v) * (fx - fw);
+            double pp = (x - v) * tmp2 - (x - w) * tmp1;
+            tmp2 = 2.0 * (tmp2 - tmp1);
+            if (tmp2 > 0.0) pp = -pp;
+            tmp2 = fabs(tmp2);
+            const double dx_temp = deltax;
+            deltax = rat;
+            if ((pp > tmp2 * (lo - x)) && (pp < tmp2 * (hi - x)) && (fabs(pp) < fabs(0.5 * tmp2 * dx_temp))) {
+                rat = pp * 1.0 / tmp2;
+                const double u = x + rat;
+                if ((u - lo) < tol2 || (hi - u) < tol2) rat = (xmid - x >= 0) ? tol1 : -tol1;
+            } else {
+                deltax = (x >= xmid) ? lo - x : hi - x;
+                rat = cg * deltax;
+            }
+        }
+        double u;
+        if (fabs(rat) < tol1) u = (rat >= 0) ? x + tol1 : x - tol1;
+        else u = x + rat;
+        const double fu = g(u); if (f.stop) return;
+        if (fu > fx) {
+            if (u < x) lo = u; else hi = u;
+            if ((fu <= fw) || (w == x)) { v = w; w = u; fv = fw; fw = fu; }
+            else if ((fu <= fv) || (v == x) || (v == w)) { v = u; fv = fu; }
+        } else {
+            if (u >= x) lo = x; else hi = x;
+            v = w; w = x; x = u;
+            fv = fw; fw = fx; fx = fu;
+        }
+    }
+    alpha_min = x;
+    fret = fx;
+}
+
+__global__ __launch_bounds__(64) void k_rscsa_search(RscsaArgs a)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n) return;
+    RscsaObjective f{a, i, 0, 0, false, a.csa0[i]};
+    for (int e = 0; e < a.E; ++e) f.ncover += a.cover[(size_t)e * a.n + i] ? 1 : 0;
+    a.nfev[i] = 0;
+    a.csa[i] = a.csa0[i];
+    a.fopt[i] = NAN;
+    if (f.ncover == 0) return;          // the reference skips residues no experiment covers
+    // _minimize_powell, N = 1
+    double x = a.csa0[i], direc = a.step;
+    double fval = f(x);
+    double x1 = x;
+    int iter = 0;
+    while (!f.stop) {
+        const double fx = fval;
+        double delta = 0.0;
+        {
+            const double fx2 = fval;
+            if (direc != 0.0) {
+                double amin = 0.0, fret = fval;
+                rscsa_line_min(f, x, direc, a.xtol * 100, amin, fret);
+                if (f.stop) break;
+                x = x + amin * direc;          // the scaled direction is a local of the loop: direc[0] itself is kept
+                fval = fret;
+            }
+            if ((fx2 - fval) > delta) delta = fx2 - fval;
+        }
+        iter += 1;
+        const double bnd = a.ftol * (fabs(fx) + fabs(fval)) + 1e-20;
+        if (2.0 * (fx - fval) <= bnd) break;
+        if (f.calls >= a.maxfun) break;
+        if (iter >= a.maxiter) break;
+        if (isnan(fx) && isnan(fval)) break;
+        double direc1 = x - x1;
+        x1 = x;
+        const double x2 = x + direc1;          // min(lmax, 1) * direc1 with lmax = 1
+        const double fx2 = f(x2);
+        if (f.stop) break;
+        if (fx > fx2) {
+            double t = 2.0 * (fx + fx2 - 2.0 * fval);
+            double temp = fx - fval - delta;
+            t *= temp * temp;
+            temp = fx - fx2;
+            t -= delta * temp * temp;
+            if (t < 0.0) {
+                if (direc1 != 0.0) {
+                    double amin = 0.0, fret = fval;
+                    rscsa_line_min(f, x, direc1, a.xtol * 100, amin, fret);
+                    if (f.stop) break;
+                    direc1 = amin * direc1;
+                    x = x + direc1;
+                    fval = fret;
+                }
+                if (direc1 != 0.0) direc = direc1;
+            }
+        }
+    }
+    a.nfev[i] = f.calls;
+    a.csa[i] = f.last;
+    a.fopt[i] = fval;
+    for (int e = 0; e < a.E; ++e) {
+        if (!a.cover[(size_t)e * a.n + i]) continue;
+        double v, dv;
+        f.closed_form(e, f.last, v, dv);
+        a.val[(size_t)e * a.n + i] = v;
+        a.err[(size_t)e * a.n + i] = dv;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -333,6 +589,61 @@ int sr_jomega_relax_f64_dev(sr_ctx *ctx, int model, const double *D, int E, cons
     a.out = out; a.Jout = Jout; a.stats = stats;
     hipLaunchKernelGGL(k_relax, dim3((unsigned)nRes, (unsigned)E), dim3(256), 0, ctx->stream, a);
     SR_HIP(hipGetLastError());
+    return 0;
+}
+
+int sr_rscsa_search_f64(sr_ctx *ctx, int E, int nRes, const double *stats, const int *column, const double *csa_prefactor,
+                        const double *noe_factor, const double *f_DD, const double *target, const double *dtarget,
+                        const unsigned char *cover, int has_err, const double *csa0, double step, double xtol, double ftol,
+                        double *csa, double *values, double *errors, double *fopt, int *nfev)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(E >= 1 && nRes >= 1, -3, "sr_rscsa_search_f64: bad sizes");
+    SR_REQUIRE(stats && column && csa_prefactor && noe_factor && f_DD && target && dtarget && cover && csa0 && csa && values &&
+               errors && fopt && nfev, -2, "sr_rscsa_search_f64: null pointer");
+    for (int e = 0; e < E; ++e)
+        SR_REQUIRE(column[e] >= 0 && column[e] <= 2, -3, "sr_rscsa_search_f64: column[%d]=%d is not 0 (R1), 1 (R2) or 2 (NOE)", e, column[e]);
+    const size_t nE = (size_t)E, nR = (size_t)nRes, EN = nE * nR;
+    const size_t nd_in = EN * 12 + 3 * nE + 2 * EN + nR;
+    double *din = (double *)sr_workspace(ctx, SR_WS_IN0, nd_in * sizeof(double));
+    int *iin = (int *)sr_workspace(ctx, SR_WS_IN1, nE * sizeof(int) + EN);
+    double *dout = (double *)sr_workspace(ctx, SR_WS_OUT0, (2 * EN + 2 * nR) * sizeof(double) + nR * sizeof(int));
+    if (!din || !iin || !dout) return -5;
+    double *p = din;
+    auto put = [&](const double *src, size_t n) -> const double * {
+        hipError_t e = hipMemcpyAsync(p, src, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return nullptr;
+        const double *r = p;
+        p += n;
+        return r;
+    };
+    RscsaArgs a;
+    a.E = E; a.n = nRes; a.has_err = has_err ? 1 : 0; a.maxfun = 1000; a.maxiter = 1000;
+    a.step = step; a.xtol = xtol; a.ftol = ftol;
+    a.stats = put(stats, EN * 12);
+    a.pref = put(csa_prefactor, nE);
+    a.cnoe = put(noe_factor, nE);
+    a.fdd = put(f_DD, nE);
+    a.y = put(target, EN);
+    a.dy = put(dtarget, EN);
+    a.csa0 = put(csa0, nR);
+    SR_REQUIRE(a.stats && a.pref && a.cnoe && a.fdd && a.y && a.dy && a.csa0, -6, "sr_rscsa_search_f64: host to device copy failed");
+    SR_HIP(hipMemcpyAsync(iin, column, nE * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    unsigned char *cov_d = (unsigned char *)(iin + nE);
+    SR_HIP(hipMemcpyAsync(cov_d, cover, EN, hipMemcpyHostToDevice, ctx->stream));
+    a.col = iin;
+    a.cover = cov_d;
+    a.val = dout; a.err = dout + EN; a.csa = dout + 2 * EN; a.fopt = a.csa + nR;
+    a.nfev = (int *)(a.fopt + nR);
+    SR_HIP(hipMemsetAsync(dout, 0, 2 * EN * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_rscsa_search, dim3((unsigned)((nRes + 63) / 64)), dim3(64), 0, ctx->stream, a);
+    SR_HIP(hipGetLastError());
+    SR_HIP(hipMemcpyAsync(values, a.val, EN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(errors, a.err, EN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(csa, a.csa, nR * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(fopt, a.fopt, nR * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(nfev, a.nfev, nR * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

@@ -242,6 +242,33 @@ class Context:
               'sr_dq_moments_f32')
         return out
 
+    # ---- residue-specific CSA search (new class API) ----
+    def rscsa_search(self, stats, column, csa_prefactor, noe_factor, f_DD, target, dtarget, cover, has_err, csa0, step,
+                     xtol=1e-4, ftol=1e-4):
+        """One-variable Powell search per residue over the closed forms of the 12 statistics (spectral_densities.py:1371-1382,
+        1430-1447).  stats (E, n, 12); target/dtarget/cover (E, n).  Returns csa (n), values (E, n), errors (E, n), fopt (n),
+        nfev (n)."""
+        stats = _f64(stats)
+        E, n = stats.shape[0], stats.shape[1]
+        if stats.shape != (E, n, 12):
+            raise ValueError('stats must be (E, n, 12)')
+        col = np.ascontiguousarray(column, dtype=np.int32)
+        pref, cn, fdd = _f64(csa_prefactor), _f64(noe_factor), _f64(f_DD)
+        y, dy = _f64(target), _f64(dtarget)
+        cov = np.ascontiguousarray(cover, dtype=np.uint8)
+        c0 = _f64(csa0)
+        if col.shape != (E,) or pref.shape != (E,) or cn.shape != (E,) or fdd.shape != (E,):
+            raise ValueError('per-experiment arrays must have E entries')
+        if y.shape != (E, n) or dy.shape != (E, n) or cov.shape != (E, n) or c0.shape != (n,):
+            raise ValueError('target, dtarget and cover must be (E, n), csa0 (n)')
+        csa, fopt = np.empty(n), np.empty(n)
+        vals, errs = np.empty((E, n)), np.empty((E, n))
+        nfev = np.empty(n, dtype=np.int32)
+        check(self.lib.sr_rscsa_search_f64(self.h, E, n, _ptr(stats), _ptr(col), _ptr(pref), _ptr(cn), _ptr(fdd), _ptr(y), _ptr(dy),
+                                           _ptr(cov), int(bool(has_err)), _ptr(c0), float(step), float(xtol), float(ftol),
+                                           _ptr(csa), _ptr(vals), _ptr(errs), _ptr(fopt), _ptr(nfev)), 'sr_rscsa_search_f64')
+        return csa, vals, errs, fopt, nfev
+
     # ---- kernel 3b ----
     def expfit_resjac(self, t, y, sigma, params, want_jac=True):
         t = _f64(np.atleast_2d(t))

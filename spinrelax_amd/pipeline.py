@@ -141,7 +141,7 @@ class DevicePipeline:
         self.reserve_cus = 0
         info = ctx.device_info()
         if reserve_cus and self.depth > 1:
-            # Mask bit i is CU i/8 of XCD i%8 on MI355X (scripts/dev_cumask.py): a multiple of 8 taken from the top
+            # Mask bit i is CU i/8 of XCD i%8 on MI355X (scripts/dev/cumask.py): a multiple of 8 taken from the top
             # keeps the 8 XCDs balanced.
             ncu = info['n_cu']
             nx = 8

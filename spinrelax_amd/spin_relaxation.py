@@ -570,13 +570,26 @@ class spinRelaxationExperiments:
             var = c * c * st[11]
         return v, (np.sqrt(max(var, 0.0)) if has_err else None)
 
-    def optimisation_loop_do_local_step(self):
-        """spectral_densities.py:1371-1382 + 1430-1447: per-residue 1-D Powell on the rsCSA objective.  Like the
-        reference, the CSA kept for a residue is the one of the LAST objective evaluation (the reference ignores
-        fmin_powell's return value and relies on the side effect of set_all_csa inside the objective)."""
-        stats = self.rscsa_statistics()
+    def rscsa_search_inputs(self):
+        """Dense (E, n) target / uncertainty / coverage arrays and the per-experiment constants of the closed forms."""
         n = self.localCtModels.nModels
-        i0, nloc = srdist.my_range(n)            # several ranks: each searches its residues, results gathered below
+        E = len(self.spinrelax)
+        y, dy, cover = np.zeros((E, n)), np.zeros((E, n)), np.zeros((E, n), dtype=np.uint8)
+        for i, cov in enumerate(self.mapExptCoverage):
+            for exptID, peakID in cov:
+                cover[exptID, i] = 1
+                y[exptID, i] = self.data[exptID]['y'][peakID]
+                if self.data[exptID]['dy'] is not None:
+                    dy[exptID, i] = self.data[exptID]['dy'][peakID]
+        col = np.array([sp.column for sp in self.spinrelax], dtype=np.int32)
+        pref = np.array([sp.angFreq.csa_prefactor() for sp in self.spinrelax])
+        cnoe = np.array([sp.time_fact * (sp.angFreq.gB.gamma / sp.angFreq.gA.gamma) for sp in self.spinrelax])
+        fdd = np.array([sp.angFreq.get_factor_DD() for sp in self.spinrelax])
+        return col, pref, cnoe, fdd, y, dy, cover
+
+    def optimisation_loop_do_local_step_host(self, stats, i0, nloc):
+        """The host form of the search (scipy's fmin_powell called per residue, as in the reference): kept as the
+        checker of the device search in tests/ -- the product path below never calls it."""
         for i in range(i0, i0 + nloc):
             cover = self.mapExptCoverage[i]
             if len(cover) == 0:
@@ -604,14 +617,40 @@ class spinRelaxationExperiments:
                 return chisq / len(cover)
             fmin_powell(objective, x0=self.get_first_csa(ind=i), direc=[spinRelaxationExperiments.dictStepSizes['rsCSA']],
                         full_output=False, disp=False)
+
+    def optimisation_loop_do_local_step(self, ctx=None):
+        """spectral_densities.py:1371-1382 + 1430-1447: per-residue 1-D Powell on the rsCSA objective, every residue's
+        search in ONE launch (sr_rscsa_search_f64: a thread per residue walks scipy's Powell / Brent iteration over the
+        closed forms of the 12 statistics).  Like the reference, the CSA kept for a residue is the one of the LAST
+        objective evaluation (the reference ignores fmin_powell's return value and relies on the side effect of
+        set_all_csa inside the objective), and the values / errors of the covered experiments are the ones of that
+        evaluation."""
+        stats = self.rscsa_statistics()
+        n = self.localCtModels.nModels
+        i0, nloc = srdist.my_range(n)            # several ranks: each searches its residues, results gathered below
+        sl = slice(i0, i0 + nloc)
+        col, pref, cnoe, fdd, y, dy, cover = self.rscsa_search_inputs()
+        has_err = self.globalRotDif.axisAvg is not None
+        csa_all = np.array(self.get_first_csa(), dtype=float)
+        if nloc > 0:
+            csa, vals, errs, _, nfev = _ctx(ctx or self.ctx).rscsa_search(
+                stats[:, sl], col, pref, cnoe, fdd, y[:, sl], dy[:, sl], cover[:, sl], has_err, csa_all[sl],
+                spinRelaxationExperiments.dictStepSizes['rsCSA'])
+            self.nObjectiveCalls += int(nfev.sum())
+            csa_all[sl] = csa
+            for e, sp in enumerate(self.spinrelax):
+                m = np.nonzero(cover[e, sl])[0]
+                sp.values[i0 + m] = vals[e, m]
+                if has_err:
+                    sp.errors[i0 + m] = errs[e, m]
         if srdist.world() > 1:
-            sl = slice(i0, i0 + nloc)
-            csa = srdist.gather_rows(np.array(self.get_first_csa())[sl], n)
+            csa_all = srdist.gather_rows(csa_all[sl], n)
             for sp in self.spinrelax:
-                sp.angFreq.gA.set_csa(csa)
                 sp.values = srdist.gather_rows(np.asarray(sp.values)[sl], n)
                 if sp.errors is not None:
                     sp.errors = srdist.gather_rows(np.asarray(sp.errors)[sl], n)
+        for sp in self.spinrelax:
+            sp.angFreq.gA.set_csa(csa_all)
 
     def perform_optimisation(self, maxCycles=10, tol=1e-6):
         """spectral_densities.py:1302-1358."""

@@ -249,3 +249,67 @@ def test_bench_json_contract():
     assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0
     assert set(c['stages_s']) >= {'ct_s', 'rotate_hist_s', 'fit_s', 'relax_s'} and c['all_cores']['cores'] >= 1 and 'cpu_fft_formulation' in c
     assert j['fit']['unfitted'] == 0
+
+
+def test_workspace_growth_while_another_stream_is_busy(synth_cache):
+    """One context driven from two streams: the C(t) call on stream A is still running (direct formulation, ~1 ms) when a
+    larger call on stream B makes the context grow the very work area A is using (the raw C(t) sums).  Growth
+    synchronises the DEVICE before the old buffer is freed (sr_core.hip:sr_workspace), so A's result must equal the
+    result of the same call made alone, and so must B's."""
+    import torch
+    from spinrelax_amd import synth
+    from spinrelax_amd.hip import Context
+    s = synth.config_shapes(3)
+    nA, nB = 16, 64
+    vecs = synth_cache(3, nB)
+    N, R, F, L = s['N'], s['R'], s['F'], s['L']
+    dev = torch.device('cuda', 0)
+    Npad = (vecs.shape[0] + 63) // 64 * 64
+    d = torch.from_numpy(vecs).to(dev)
+    soa = torch.zeros((nB, 3, Npad), device=dev, dtype=torch.float32)
+
+    def run_alone(nV):
+        c = Context(0)
+        c.set_option('ct_fft', 0)
+        c.set_stream(0)
+        c.pack_soa_dev(d.data_ptr(), vecs.shape[0], nB, 0, nB, soa.data_ptr(), Npad)
+        Ct = torch.empty((L, nV), device=dev, dtype=torch.float64)
+        dCt = torch.empty_like(Ct)
+        c.ct_palmer_dev(soa.data_ptr(), Npad, R, F, nV, Ct.data_ptr(), dCt.data_ptr())
+        torch.cuda.synchronize()
+        out = Ct.cpu().numpy(), dCt.cpu().numpy()
+        c.close()
+        return out
+
+    refA, refB = run_alone(nA), run_alone(nB)
+    assert np.array_equal(refA[0], refB[0][:, :nA])
+    c = Context(0)
+    c.set_option('ct_fft', 0)
+    sA, sB = c.stream_create(), c.stream_create()
+    CtA = torch.empty((L, nA), device=dev, dtype=torch.float64)
+    dCtA = torch.empty_like(CtA)
+    CtB = torch.empty((L, nB), device=dev, dtype=torch.float64)
+    dCtB = torch.empty_like(CtB)
+    torch.cuda.synchronize()
+    try:
+        for _ in range(3):
+            c.set_stream(sA)
+            c.ct_palmer_dev(soa.data_ptr(), Npad, R, F, nA, CtA.data_ptr(), dCtA.data_ptr())
+            c.set_stream(sB)
+            c.ct_palmer_dev(soa.data_ptr(), Npad, R, F, nB, CtB.data_ptr(), dCtB.data_ptr())    # grows the sums' area
+            c.device_sync()
+            assert np.array_equal(CtA.cpu().numpy(), refA[0]) and np.array_equal(dCtA.cpu().numpy(), refA[1])
+            assert np.array_equal(CtB.cpu().numpy(), refB[0]) and np.array_equal(dCtB.cpu().numpy(), refB[1])
+            # a fresh context for the next round so that the area has to grow again
+            c.set_stream(0)
+            c.stream_destroy(sA)
+            c.stream_destroy(sB)
+            c.close()
+            c = Context(0)
+            c.set_option('ct_fft', 0)
+            sA, sB = c.stream_create(), c.stream_create()
+    finally:
+        c.set_stream(0)
+        c.stream_destroy(sA)
+        c.stream_destroy(sB)
+        c.close()

@@ -24,7 +24,7 @@ One JSON line is printed by rank 0 (contract in the task statement) with extra o
                 deterministic) / duration against the FP64 vector peak.  Durations: `in_pipeline_ms` from HIP events placed
                 around the launch on the stream it runs on, inside the timed region; `alone_ms` the same launch by itself
                 on the whole chip after the timed region; `cu_ms_per_batch` = 256 CUs x the time a batch's worth of that
-                kernel takes when the chip is saturated with it (the fit: 8 batches' residues, longest first, in one launch / 8).
+                kernel takes when the chip is saturated with it (the fit: 32 batches' residues, longest first, in one launch / 32).
   roofline      the `kernels` entry with the largest cu_ms_per_batch (the kernel that occupies most of the chip), in the
                 contract's shape {bound, achieved, peak, unit, frac, traffic}; `direct_equivalent` keeps the reference
                 formulation's 8 flop / 24 B per triple over the C(t) kernel's duration for comparison only.
@@ -87,6 +87,7 @@ def parse():
     ap.add_argument('--vectors', type=int, default=None, help='vectors per GPU (default: the config value)')
     ap.add_argument('--reserve-cus', type=int, default=0, help='CUs kept free of the C(t)/histogram kernels for the latency-bound fit kernels (CU-masked stream; 0 = no partition)')
     ap.add_argument('--fits-on-reserved-only', type=int, default=1, help='1/0: confine the fit kernels to the reserved CUs (strict partition)')
+    ap.add_argument('--aux-cus', type=int, default=0, help='CUs set aside for the pack / histogram stream (multiple of 8; compute kernels are masked off them)')
     ap.add_argument('--fit-waves', type=int, default=0, help='wavefronts per residue in the model-order search (0 = library default)')
     ap.add_argument('--fit-lds', type=int, default=-1, help='1/0: keep residue data in LDS during the fits (-1 = library default)')
     ap.add_argument('--dev-skip-fits', action='store_true', help='DEVELOPMENT ONLY (invalid as a benchmark): leave the fits and the relaxation kernel out, to see the floor the C(t) side alone sets')
@@ -253,7 +254,7 @@ def main():
     triples = synth.exact_triples(s['R'], s['F'], V)
     pkw = dict(q_rot=q, Diso=synth.DISO, aniso=aniso, field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA)
     pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], depth=args.depth,
-                          stream=torch.cuda.Stream(device=dev), reserve_cus=args.reserve_cus,
+                          stream=torch.cuda.Stream(device=dev), reserve_cus=args.reserve_cus, aux_cus=args.aux_cus,
                           fits_on_reserved_only=bool(args.fits_on_reserved_only), hist_on_aux=not args.hist_on_main, **pkw)
     stream = pipe.main
     if args.dev_skip_fits:
@@ -375,12 +376,12 @@ def main():
             ctx.set_option('ct_fft', 2 if args.ct_fft < 0 else args.ct_fft)
             with torch.cuda.stream(st1):
                 p1.stage_ct(s0)                 # restore the slot's sums / C(t) from the production kernel
-        # The model-order search with the chip saturated: 8 batches' residues in ONE launch, the expensive residues first
+        # The model-order search with the chip saturated: 32 batches' residues in ONE launch, the expensive residues first
         # (sorted by the evaluations they needed in the batch above).  A lone launch lasts as long as its slowest residue
         # (~10 ms for one 286-evaluation fit); with several batches in flight that tail overlaps the next batches' work,
         # and what a batch costs the chip is (sum of the residues' solve times) / (resident workgroups) -- which is what
         # this launch measures, because longest-first dispatch leaves no tail.
-        K = 8
+        K = int(os.environ.get('SR_BENCH_SATK', 32))
         f64 = dict(device=dev, dtype=torch.float64)
         i32 = dict(device=dev, dtype=torch.int32)
         nO, Pmax, Kmax = len(listDoG), max(listDoG), max(listDoG) // 2
@@ -475,7 +476,7 @@ def main():
                      cu_ms_per_batch=sat * N_CU if sat else None, residues=V, evaluations_per_batch=nfev_step,
                      residues_per_s=V / (tref * 1e-3), evaluations_per_s=nfev_step / (tref * 1e-3),
                      peak=PEAK_FP64_TFLOPS, unit='TFLOP/s',
-                     note='rates over the saturated duration (8 batches, longest residues first, in one launch / 8): the time the chip needs per batch when '
+                     note='rates over the saturated duration (32 batches, longest residues first, in one launch / 32): the time the chip needs per batch when '
                           'it is full of fits; a lone launch lasts as long as its slowest residue (alone_ms)')
             if fflop:
                 e['work_per_launch'] = float(fflop)

@@ -1144,8 +1144,8 @@ int launch_search(sr_ctx *ctx, const SearchArgs &a)
 {
     switch (ctx->fit_waves) {
         case 1: return launch_search_w<NMAX, 1>(ctx, a);
-        case 4: return launch_search_w<NMAX, 4>(ctx, a);
-        default: return launch_search_w<NMAX, 2>(ctx, a);
+        case 2: return launch_search_w<NMAX, 2>(ctx, a);
+        default: return launch_search_w<NMAX, 4>(ctx, a);
     }
 }
 
@@ -1208,8 +1208,8 @@ int launch_trf(sr_ctx *ctx, const FitArgs &a)
 {
     switch (ctx->fit_waves) {
         case 1: return launch_trf_w<N, 1>(ctx, a);
-        case 4: return launch_trf_w<N, 4>(ctx, a);
-        default: return launch_trf_w<N, 2>(ctx, a);
+        case 2: return launch_trf_w<N, 2>(ctx, a);
+        default: return launch_trf_w<N, 4>(ctx, a);
     }
 }
 

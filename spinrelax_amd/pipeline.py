@@ -118,7 +118,7 @@ class _Slot:
 class DevicePipeline:
     def __init__(self, ctx, device, frames, V, R, F, dt, q_rot=None, Diso=None, aniso=None, field_MHz=(600.133,),
                  zeta=0.890023, histBinX=72, listDoG=(2, 3, 5, 7, 9), csa=None, depth=1, stream=None, reserve_cus=0,
-                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None, hist_on_aux=True, v0=0):
+                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None, hist_on_aux=True, v0=0, aux_cus=0):
         self.ctx = ctx
         self.dev = device
         self.frames, self.V, self.R, self.F, self.dt = frames, V, R, F, dt
@@ -150,6 +150,21 @@ class DevicePipeline:
             self.main = self._masked_stream(range(ncu - r), ncu)
             if fits_on_reserved_only:
                 resv_words = self._mask_words(range(ncu - r, ncu), ncu)
+        # Bandwidth kernels on their own few CUs.  The compute kernels (C(t): 249 VGPRs, fits: 256) fill the register file
+        # of every CU they run on, so a pack / histogram wave launched beside them only gets a slot when a compute
+        # workgroup retires -- the HBM-bound and the issue-bound work then take turns instead of overlapping.  With
+        # `aux_cus` CUs (a multiple of 8: the same number from every XCD) set aside for the auxiliary stream and the
+        # compute streams masked off them, pack + histogram stream at what those CUs can pull from HBM, fully beside
+        # the compute kernels on the rest of the chip.
+        self.aux_cus = 0
+        aux_words = None
+        if aux_cus and self.depth > 1 and not reserve_cus:
+            ncu = info['n_cu']
+            r = min(ncu - 8, (int(aux_cus) + 7) // 8 * 8)
+            self.aux_cus = r
+            self.main = self._masked_stream(range(ncu - r), ncu)
+            resv_words = self._mask_words(range(ncu - r), ncu)          # fits: same complement as the main stream
+            aux_words = self._mask_words(range(ncu - r, ncu), ncu)
         Pmax = max(self.listDoG)
         E = len(self.fields)
         need_fitwork = True      # per-batch weight scratch for residues that are not LDS-resident (concurrent launches)
@@ -162,7 +177,7 @@ class DevicePipeline:
         # batch k (bandwidth / FP64 work) run beside the C(t) launch of batch k (FP32 issue bound) instead of in line with it
         self.soa = torch.empty((V, 3, self.Npad), device=device, dtype=torch.float32)
         self.soa_bufs = [self.soa] + ([torch.empty_like(self.soa)] if self.depth > 1 else [])
-        self.aux = torch.cuda.Stream(device=device) if self.depth > 1 else None
+        self.aux = (self._borrow(aux_words) if aux_words is not None else torch.cuda.Stream(device=device)) if self.depth > 1 else None
         self._packed_ev = [None, None]
         self.hist_on_aux = hist_on_aux
         # the mean / std over the chunks and the transposes only feed this batch's fits: they run on the batch's own

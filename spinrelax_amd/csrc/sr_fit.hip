@@ -47,13 +47,18 @@ struct FitArgs {
 
 __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 
-// Two instruction-count reductions that are implemented, give bit-identical fits, and are OFF because they lose on
-// gfx950 (cfg3 benchmark data, model-order search alone / whole pipeline step):
-//   SR_FIT_LEADER=1  only the leader wave runs the n x n algebra and broadcasts the trial point   14.5 ms / 10.5 ms
-//   SR_FIT_MARK=1,2  shared-divisor (Markstein) division for t/tau (1) and the FD quotient (2)     12.7, 16.8 / 10.4, 11.0
-//   both off                                                                                      12.4 ms / 10.4 ms
-// The kernel lives at the 256-register limit of two waves per SIMD; the extra live values (reciprocals, the
-// broadcast state) turn into scratch spills inside the Jacobian loop that cost more than the instructions saved.
+// Instruction-count reductions, all bit-identical in their results (cfg3 benchmark batch, model-order search alone /
+// saturated per batch / whole pipeline step at 20 steps):
+//   SR_FIT_MARK=2 (default)  shared-divisor (Markstein) division for t/tau and for the forward-difference quotient, the
+//                            divisors and their reciprocals held in SGPRs (uni()), no branch:      9.25 / 0.868 / 3.30 ms
+//   SR_FIT_MARK=1            t/tau only                                                           9.39 / 0.905 / 3.43
+//   SR_FIT_MARK=0            IEEE divisions                                                       9.87 / 0.937 / 3.43
+//   SR_FIT_LEADER=1          only the leader wave runs the n x n algebra and broadcasts the trial point: within 2 % either
+//                            way (9.63 against 9.86 ms alone on the MARK=0 build), left off.
+// Round 1 had tried Markstein with the reciprocals in VGPRs and a branch for huge quotients: the kernel lives at the
+// 256-register limit of two waves per SIMD, the extra live values spilled inside the Jacobian loop and the branch kept
+// the scheduler from interleaving the independent exponentials of a point (12.7 -> 16.8 ms).  Uniform values in SGPRs
+// cost no vector registers; the Jacobian loop went from 535 to 437 instructions per point at n = 9.
 #ifndef SR_FIT_LEADER
 #define SR_FIT_LEADER 0
 #endif
@@ -61,22 +66,38 @@ __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 #define SR_FIT_LF_LDS 1      // Cholesky factor in a per-wave LDS area instead of 90 VGPRs
 #endif
 #ifndef SR_FIT_MARK
-#define SR_FIT_MARK 0
+#define SR_FIT_MARK 2
 #endif
 
 // a / b for a divisor b shared by many numerators, with r = 1.0 / b computed once (correctly rounded).  q0 = a*r is
 // within 2 ulp; one residual correction makes it faithful, the second gives the correctly rounded quotient
-// (Markstein 1990; the same tail v_div_fmas_f64 executes) -- 5 instructions instead of the ~14 of a full IEEE
+// (Markstein 1990; the same tail v_div_fmas_f64 executes) -- 5 instructions instead of the 11 of a full IEEE
 // division with its scaling.  Exception the theorem leaves open: divisors whose significand is all ones.
-// Huge quotients (tau at its lower bound) take the ordinary division.
+// Divisor and reciprocal are workgroup-uniform: uni() moves them into SGPRs (v_fma_f64 takes one scalar operand), so
+// the hoisted reciprocals cost no VGPRs in loops that already sit at the register limit.
+__device__ __forceinline__ double uni(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double div_shared(double a, double b, double r)
 {
     double q = a * r;
-    if (!(fabs(q) <= 1e290)) return a / b;
     double e = fma(-b, q, a);
     q = fma(e, r, q);
     e = fma(-b, q, a);
     return fma(e, r, q);
+}
+// The quotient -t/tau only feeds exp(): when a*r is huge or infinite (tau at its lower bound, r = inf: the residual
+// would be NaN) exp() of it is 0 whatever its last bits, so the uncorrected product stands in -- a select, no branch
+// (a branch per division keeps the scheduler from interleaving the K independent exponentials of a point).
+__device__ __forceinline__ double div_shared_for_exp(double a, double b, double r)
+{
+    const double q0 = a * r;
+    const double q = div_shared(a, b, r);
+    return fabs(q0) <= 1e290 ? q : q0;
 }
 
 // ---- model: curvefit_exponential, fitting_Ct_functions.py:419-427 -----------------------------
@@ -101,16 +122,19 @@ struct Model {
 #pragma unroll
         for (int k = 0; k < K; ++k) e[k] = exp((-1.0 * t) / x[K + k]);
     }
-    // the same with rtau[k] = 1.0 / tau_k hoisted out of the loop over the data points
-    __device__ static __forceinline__ void recips(const double *x, double *rtau)
+    // the same with the divisors tau_k and rtau[k] = 1.0 / tau_k hoisted out of the loop over the data points (SGPRs)
+    __device__ static __forceinline__ void recips(const double *x, double *tau_u, double *rtau)
     {
 #pragma unroll
-        for (int k = 0; k < K; ++k) rtau[k] = 1.0 / x[K + k];
+        for (int k = 0; k < K; ++k) {
+            tau_u[k] = SR_FIT_MARK >= 1 ? uni(x[K + k]) : x[K + k];
+            rtau[k] = SR_FIT_MARK >= 1 ? uni(1.0 / x[K + k]) : 0.0;
+        }
     }
-    __device__ static __forceinline__ void exps(const double *x, const double *rtau, double t, double *e)
+    __device__ static __forceinline__ void exps(const double *tau_u, const double *rtau, double t, double *e)
     {
 #pragma unroll
-        for (int k = 0; k < K; ++k) e[k] = exp(SR_FIT_MARK >= 1 ? div_shared(-1.0 * t, x[K + k], rtau[k]) : (-1.0 * t) / x[K + k]);
+        for (int k = 0; k < K; ++k) e[k] = exp(SR_FIT_MARK >= 1 ? div_shared_for_exp(-1.0 * t, tau_u[k], rtau[k]) : (-1.0 * t) / tau_u[k]);
     }
     __device__ static __forceinline__ double value(const double *x, const double *e)
     {
@@ -534,11 +558,11 @@ __device__ __forceinline__ double eval_f(const R &T, const double *x, bool &fini
     const int tid = T.tid, L = T.L;
     constexpr int NTH = R::NTH;
     double acc = 0.0, bad = 0.0;
-    double rtau[K > 0 ? K : 1];
-    M::recips(x, rtau);
+    double tau_u[K > 0 ? K : 1], rtau[K > 0 ? K : 1];
+    M::recips(x, tau_u, rtau);
     for (int l = tid; l < L; l += NTH) {
         double e[K > 0 ? K : 1];
-        M::exps(x, rtau, T.ld_t(l), e);
+        M::exps(tau_u, rtau, T.ld_t(l), e);
         double f;
         {
 #pragma clang fp contract(off)
@@ -576,12 +600,15 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
         if (!fitting) hi = (ud >= ld) ? ud : -ld;
         h[i] = hi;
         dx[i] = (x[i] + hi) - x[i];
-        rdx[i] = 1.0 / dx[i];
+        if (SR_FIT_MARK >= 2) { dx[i] = uni(dx[i]); rdx[i] = uni(1.0 / dx[i]); }
     }
-    double rtau[K > 0 ? K : 1], rtau_h[K > 0 ? K : 1];
-    M::recips(x, rtau);
+    double tau_u[K > 0 ? K : 1], rtau[K > 0 ? K : 1], tauh_u[K > 0 ? K : 1], rtau_h[K > 0 ? K : 1];
+    M::recips(x, tau_u, rtau);
 #pragma unroll
-    for (int k = 0; k < K; ++k) rtau_h[k] = 1.0 / (x[K + k] + h[K + k]);
+    for (int k = 0; k < K; ++k) {
+        tauh_u[k] = SR_FIT_MARK >= 1 ? uni(x[K + k] + h[K + k]) : 0.0;
+        rtau_h[k] = SR_FIT_MARK >= 1 ? uni(1.0 / (x[K + k] + h[K + k])) : 0.0;
+    }
     double Aacc[NT], gacc[N];
 #pragma unroll
     for (int i = 0; i < NT; ++i) Aacc[i] = 0.0;
@@ -590,7 +617,7 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
     for (int l = tid; l < L; l += NTH) {
         const double tl = T.ld_t(l), w = T.ld_w(l), yl = T.ld_y(l);
         double e[K > 0 ? K : 1], Jr[N], f0;
-        M::exps(x, rtau, tl, e);
+        M::exps(tau_u, rtau, tl, e);
         {
 #pragma clang fp contract(off)
             f0 = w * (M::value(x, e) - yl);
@@ -606,7 +633,7 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
 #pragma unroll
                 for (int k = 0; k < K; ++k) ei[k] = e[k];
                 if (i >= K && i < 2 * K)
-                    ei[i - K] = exp(SR_FIT_MARK >= 1 ? div_shared(-1.0 * tl, xi[i], rtau_h[i - K]) : (-1.0 * tl) / xi[i]);
+                    ei[i - K] = exp(SR_FIT_MARK >= 1 ? div_shared_for_exp(-1.0 * tl, tauh_u[i - K], rtau_h[i - K]) : (-1.0 * tl) / xi[i]);
                 double fi;
                 {
 #pragma clang fp contract(off)

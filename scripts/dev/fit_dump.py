@@ -16,5 +16,7 @@ for tag in ('cfg1', 'cfg2', 'cfg3s'):
             k = '%s_%d_%d' % (tag, nP, an)
             out[k + '_popt'] = popt; out[k + '_chi'] = chi; out[k + '_status'] = status; out[k + '_nfev'] = nfev
             out[k + '_dP'] = np.sqrt(np.abs(np.diagonal(pcov, axis1=1, axis2=2)))
-np.savez(os.path.join(ROOT, 'gpurun_out', 'fit_dump.npz'), **out)
+name = sys.argv[1] if len(sys.argv) > 1 else 'fit_dump'
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+np.savez(os.path.join(ROOT, 'gpurun_out', name + '.npz'), **out)
 print('ok')

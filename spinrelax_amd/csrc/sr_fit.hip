@@ -49,10 +49,12 @@ __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 
 // Instruction-count reductions, all bit-identical in their results (cfg3 benchmark batch, model-order search alone /
 // saturated per batch / whole pipeline step at 20 steps):
-//   SR_FIT_MARK=2 (default)  shared-divisor (Markstein) division for t/tau and for the forward-difference quotient, the
-//                            divisors and their reciprocals held in SGPRs (uni()), no branch:      9.25 / 0.868 / 3.30 ms
-//   SR_FIT_MARK=1            t/tau only                                                           9.39 / 0.905 / 3.43
-//   SR_FIT_MARK=0            IEEE divisions                                                       9.87 / 0.937 / 3.43
+//   SR_FIT_MARK=3 (default)  as 2, and exp(-t/tau) as one fused sequence (the device library's exp() without the selects a
+//                            non-positive argument cannot need):                                   8.95 / 0.836 / 3.40 ms (20 steps)
+//   SR_FIT_MARK=2            shared-divisor (Markstein) division for t/tau and for the forward-difference quotient, the
+//                            divisors and their reciprocals held in SGPRs (uni()), no branch:      9.25 / 0.868 / 3.45 ms
+//   SR_FIT_MARK=1            t/tau only                                                           9.39 / 0.905
+//   SR_FIT_MARK=0            IEEE divisions                                                       9.87 / 0.937 / 3.55
 //   SR_FIT_LEADER=1          only the leader wave runs the n x n algebra and broadcasts the trial point: within 2 % either
 //                            way (9.63 against 9.86 ms alone on the MARK=0 build), left off.
 // Round 1 had tried Markstein with the reciprocals in VGPRs and a branch for huge quotients: the kernel lives at the
@@ -66,7 +68,7 @@ __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 #define SR_FIT_LF_LDS 1      // Cholesky factor in a per-wave LDS area instead of 90 VGPRs
 #endif
 #ifndef SR_FIT_MARK
-#define SR_FIT_MARK 2
+#define SR_FIT_MARK 3
 #endif
 
 // a / b for a divisor b shared by many numerators, with r = 1.0 / b computed once (correctly rounded).  q0 = a*r is
@@ -98,6 +100,34 @@ __device__ __forceinline__ double div_shared_for_exp(double a, double b, double 
     const double q0 = a * r;
     const double q = div_shared(a, b, r);
     return fabs(q0) <= 1e290 ? q : q0;
+}
+// exp(a / b) for a <= 0 < b with the quotient formed as above: the instruction sequence of the device library's
+// exp() (ROCm 7.2 ocml, read off its ISA: argument reduction by ln2 hi/lo, degree-11 polynomial in Horner form, ldexp)
+// minus what a non-positive argument cannot need -- the overflow select -- and with the underflow select doubling as
+// the guard for huge / infinite quotients (tested on the uncorrected product, which differs from the quotient by two
+// ulp at most: either side of -1075 the result is 0).  Same bits as exp(a / b) wherever that is not 0 or 1 ulp of
+// the threshold (scripts/dev/fit_dump.py: every fit of the fixtures ends on identical parameters); 25 instructions
+// instead of 11 + 23.
+__device__ __forceinline__ double exp_neg_quotient(double a, double b, double r)
+{
+    const double q0 = a * r;
+    const double q = div_shared(a, b, r);
+    const double dn = rint(q * 0x1.71547652b82fep+0);
+    double t = fma(-0x1.62e42fefa39efp-1, dn, q);
+    t = fma(-0x1.abc9e3b39803fp-56, dn, t);
+    double p = fma(0x1.ade156a5dcb37p-26, t, 0x1.28af3fca7ab0cp-22);
+    p = fma(t, p, 0x1.71dee623fde64p-19);
+    p = fma(t, p, 0x1.a01997c89e6b0p-16);
+    p = fma(t, p, 0x1.a01a014761f6ep-13);
+    p = fma(t, p, 0x1.6c16c1852b7b0p-10);
+    p = fma(t, p, 0x1.1111111122322p-7);
+    p = fma(t, p, 0x1.55555555502a1p-5);
+    p = fma(t, p, 0x1.5555555555511p-3);
+    p = fma(t, p, 0x1.000000000000bp-1);
+    p = fma(t, p, 1.0);
+    p = fma(t, p, 1.0);
+    const double z = ldexp(p, (int)dn);
+    return q0 >= -1075.0 ? z : 0.0;
 }
 
 // ---- model: curvefit_exponential, fitting_Ct_functions.py:419-427 -----------------------------
@@ -134,7 +164,8 @@ struct Model {
     __device__ static __forceinline__ void exps(const double *tau_u, const double *rtau, double t, double *e)
     {
 #pragma unroll
-        for (int k = 0; k < K; ++k) e[k] = exp(SR_FIT_MARK >= 1 ? div_shared_for_exp(-1.0 * t, tau_u[k], rtau[k]) : (-1.0 * t) / tau_u[k]);
+        for (int k = 0; k < K; ++k) e[k] = SR_FIT_MARK >= 3 ? exp_neg_quotient(-1.0 * t, tau_u[k], rtau[k])
+                                                       : exp(SR_FIT_MARK >= 1 ? div_shared_for_exp(-1.0 * t, tau_u[k], rtau[k]) : (-1.0 * t) / tau_u[k]);
     }
     __device__ static __forceinline__ double value(const double *x, const double *e)
     {
@@ -633,7 +664,8 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
 #pragma unroll
                 for (int k = 0; k < K; ++k) ei[k] = e[k];
                 if (i >= K && i < 2 * K)
-                    ei[i - K] = exp(SR_FIT_MARK >= 1 ? div_shared_for_exp(-1.0 * tl, tauh_u[i - K], rtau_h[i - K]) : (-1.0 * tl) / xi[i]);
+                    ei[i - K] = SR_FIT_MARK >= 3 ? exp_neg_quotient(-1.0 * tl, tauh_u[i - K], rtau_h[i - K])
+                                                   : exp(SR_FIT_MARK >= 1 ? div_shared_for_exp(-1.0 * tl, tauh_u[i - K], rtau_h[i - K]) : (-1.0 * tl) / xi[i]);
                 double fi;
                 {
 #pragma clang fp contract(off)

@@ -64,6 +64,9 @@ __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 #ifndef SR_FIT_LEADER
 #define SR_FIT_LEADER 0
 #endif
+#ifndef SR_FIT_REDUCE_MANY
+#define SR_FIT_REDUCE_MANY 1   // lane sums of J^T J and J^T f by the register-halving reduction (sr_internal.h)
+#endif
 #ifndef SR_FIT_LF_LDS
 #define SR_FIT_LF_LDS 1      // Cholesky factor in a per-wave LDS area instead of 90 VGPRs
 #endif
@@ -640,11 +643,10 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
         tauh_u[k] = SR_FIT_MARK >= 1 ? uni(x[K + k] + h[K + k]) : 0.0;
         rtau_h[k] = SR_FIT_MARK >= 1 ? uni(1.0 / (x[K + k] + h[K + k])) : 0.0;
     }
-    double Aacc[NT], gacc[N];
+    double acc[NT + N];                       // J^T J (packed) followed by J^T f: reduced together below
+    double *Aacc = acc, *gacc = acc + NT;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) Aacc[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) gacc[i] = 0.0;
+    for (int i = 0; i < NT + N; ++i) acc[i] = 0.0;
     for (int l = tid; l < L; l += NTH) {
         const double tl = T.ld_t(l), w = T.ld_w(l), yl = T.ld_y(l);
         double e[K > 0 ? K : 1], Jr[N], f0;
@@ -693,15 +695,23 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
     {
         const int lane = tid & 63, wave = tid >> 6;
         double *r = T.red();
+        if (SR_FIT_REDUCE_MANY && NT + N <= 64) {
+            // all NT + N lane sums in ~220 instructions (sr_wave_sum_many_f64) instead of 25 each; the lane that ends up
+            // with value k's total stores it
+            const double tot = sr_wave_sum_many_f64<(NT + N <= 64 ? NT + N : 1)>(acc, lane);
+            const int k = sr_reduced_index(lane);
+            if (k < NT + N) r[wave * kRedStride + k] = tot;
+        } else {
 #pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            const double w = wsum(Aacc[k]);
-            if (lane == 0) r[wave * kRedStride + k] = w;
-        }
+            for (int k = 0; k < NT; ++k) {
+                const double w = wsum(Aacc[k]);
+                if (lane == 0) r[wave * kRedStride + k] = w;
+            }
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const double w = wsum(gacc[k]);
-            if (lane == 0) r[wave * kRedStride + NT + k] = w;
+            for (int k = 0; k < N; ++k) {
+                const double w = wsum(gacc[k]);
+                if (lane == 0) r[wave * kRedStride + NT + k] = w;
+            }
         }
         __syncthreads();
         for (int k = tid; k < NT; k += NTH) {

@@ -136,4 +136,88 @@ __device__ __forceinline__ double sr_wave_sum_f64(double v)
     const double r2 = sr_readlane_f64(v, 32), r3 = sr_readlane_f64(v, 48);
     return (r0 + r1) + (r2 + r3);
 }
+
+// ---- many sums at once: NV values per lane -> lane L ends up with the 64-lane total of value bitrev6(L) ------------
+// Reducing NV values one by one costs NV x (4 DPP steps + 8 readlanes + 3 adds) ~ 25 instructions each; the fit kernel's
+// Jacobian reduces 54 (J^T J and J^T f at n = 9): 1 350 instructions per wave, a third of the Jacobian pass itself.
+// Here every level HALVES the number of live registers instead: for a pair of values (a, b), the lanes whose level bit is
+// 0 keep a and receive the partner lane's a, the others keep b and receive the partner's b -- one exchange and one add
+// turn two registers into one.  54 -> 27 -> 14 -> 7 -> 4 -> 2 -> 1 registers: ~220 instructions.
+//   level 1, 2: lane bits 5 and 4 with v_permlane32_swap / v_permlane16_swap (gfx950: swap the upper half / the odd
+//               rows of one register with the lower half / the even rows of the other: 2 instructions per double)
+//   level 3, 4: bits 3 and 2 inside a 16-lane row: row_mirror / row_half_mirror DPP moves under bank masks
+//   level 5, 6: bits 1 and 0 inside a quad: quad_perm DPP moves + per-lane selects
+// Association order (fixed, the same for every value): lanes are paired l <-> l+32, then rows r <-> r^1, then i <-> 15-i
+// inside a row, i <-> 7-i inside its halves, i <-> 3-i inside its quads, finally neighbours.  A missing partner value
+// (odd count) is 0, which adds exactly.
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ int sr_dpp_i32(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, BANK_MASK, false);
+}
+
+template <int LEVEL>
+__device__ __forceinline__ double sr_reduce_pair(double a, double b, int lane)
+{
+    union U { double d; int i[2]; unsigned u[2]; };
+    U ua, ub, k, t;
+    ua.d = a; ub.d = b;
+    if (LEVEL == 1) {            // after the swap: ua = [a.lo32, b.lo32], ub = [a.hi32, b.hi32]
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            auto r = __builtin_amdgcn_permlane32_swap(ua.u[h], ub.u[h], false, false);
+            ua.u[h] = r[0]; ub.u[h] = r[1];
+        }
+        return ua.d + ub.d;
+    } else if (LEVEL == 2) {     // rows: ua = [a0, b0, a2, b2], ub = [a1, b1, a3, b3]
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            auto r = __builtin_amdgcn_permlane16_swap(ua.u[h], ub.u[h], false, false);
+            ua.u[h] = r[0]; ub.u[h] = r[1];
+        }
+        return ua.d + ub.d;
+    } else if (LEVEL == 3 || LEVEL == 4) {
+        constexpr int ctrl = LEVEL == 3 ? 0x140 : 0x141;            // row_mirror / row_half_mirror
+        constexpr int m0 = LEVEL == 3 ? 0x3 : 0x5, m1 = LEVEL == 3 ? 0xC : 0xA;   // banks whose level bit is 0 / 1
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            t.i[h] = sr_dpp_i32<ctrl, m0>(0, ua.i[h]);               // bit 0 lanes: the partner's a
+            t.i[h] = sr_dpp_i32<ctrl, m1>(t.i[h], ub.i[h]);          // bit 1 lanes: the partner's b
+            k.i[h] = sr_dpp_i32<0xE4, m1>(ua.i[h], ub.i[h]);         // keep a (bit 0 lanes) or b (bit 1 lanes)
+        }
+        return k.d + t.d;
+    } else {
+        constexpr int ctrl = LEVEL == 5 ? 0x1B : 0xB1;               // quad_perm [3,2,1,0] / [1,0,3,2]
+        const bool bit = (lane & (LEVEL == 5 ? 2 : 1)) != 0;
+        U s;
+        k.d = bit ? b : a;
+        s.d = bit ? a : b;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) t.i[h] = sr_dpp_i32<ctrl, 0xF>(0, s.i[h]);
+        return k.d + t.d;
+    }
+}
+
+template <int LEVEL, int N>
+__device__ __forceinline__ void sr_reduce_level(double *v, int lane)
+{
+#pragma unroll
+    for (int m = 0; m < (N + 1) / 2; ++m) v[m] = sr_reduce_pair<LEVEL>(v[2 * m], 2 * m + 1 < N ? v[2 * m + 1] : 0.0, lane);
+}
+
+// v[0 .. NV) per lane, NV <= 64 (destroyed); returns the total of value sr_reduced_index(lane) (garbage when that index
+// is >= NV)
+template <int NV>
+__device__ __forceinline__ double sr_wave_sum_many_f64(double *v, int lane)
+{
+    constexpr int N1 = (NV + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2, N5 = (N4 + 1) / 2;
+    sr_reduce_level<1, NV>(v, lane);
+    sr_reduce_level<2, N1>(v, lane);
+    sr_reduce_level<3, N2>(v, lane);
+    sr_reduce_level<4, N3>(v, lane);
+    sr_reduce_level<5, N4>(v, lane);
+    sr_reduce_level<6, N5>(v, lane);
+    return v[0];
+}
+__device__ __forceinline__ int sr_reduced_index(int lane) { return (int)(__builtin_bitreverse32((unsigned)lane) >> 26); }
 #endif

@@ -47,7 +47,7 @@ struct FitArgs {
 
 __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 
-// Instruction-count reductions, all bit-identical in their results (cfg3 benchmark batch, model-order search alone /
+// Instruction-count reductions (bit-identical results unless noted; cfg3 benchmark batch, model-order search alone /
 // saturated per batch / whole pipeline step at 20 steps):
 //   SR_FIT_MARK=3 (default)  as 2, and exp(-t/tau) as one fused sequence (the device library's exp() without the selects a
 //                            non-positive argument cannot need):                                   8.95 / 0.836 / 3.40 ms (20 steps)
@@ -55,14 +55,16 @@ __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 //                            divisors and their reciprocals held in SGPRs (uni()), no branch:      9.25 / 0.868 / 3.45 ms
 //   SR_FIT_MARK=1            t/tau only                                                           9.39 / 0.905
 //   SR_FIT_MARK=0            IEEE divisions                                                       9.87 / 0.937 / 3.55
-//   SR_FIT_LEADER=1          only the leader wave runs the n x n algebra and broadcasts the trial point: within 2 % either
-//                            way (9.63 against 9.86 ms alone on the MARK=0 build), left off.
+//   SR_FIT_LEADER=1 (default) only the leader wave runs the n x n algebra and broadcasts the trial point through LDS: 2 % in
+//                            every measure once the reductions below were out of the way (6.69 / 0.728 against 6.84 / 0.746).
+//   SR_FIT_REDUCE_MANY=1 (default) the 54 lane sums of a Jacobian by the register-halving reduction of sr_internal.h
+//                            (different association: the fits move in their last bits): 8.95 -> 6.85 / 0.832 -> 0.745
 // Round 1 had tried Markstein with the reciprocals in VGPRs and a branch for huge quotients: the kernel lives at the
 // 256-register limit of two waves per SIMD, the extra live values spilled inside the Jacobian loop and the branch kept
 // the scheduler from interleaving the independent exponentials of a point (12.7 -> 16.8 ms).  Uniform values in SGPRs
 // cost no vector registers; the Jacobian loop went from 535 to 437 instructions per point at n = 9.
 #ifndef SR_FIT_LEADER
-#define SR_FIT_LEADER 0
+#define SR_FIT_LEADER 1
 #endif
 #ifndef SR_FIT_REDUCE_MANY
 #define SR_FIT_REDUCE_MANY 1   // lane sums of J^T J and J^T f by the register-halving reduction (sr_internal.h)

@@ -88,12 +88,14 @@ def parse():
     ap.add_argument('--reserve-cus', type=int, default=0, help='CUs kept free of the C(t)/histogram kernels for the latency-bound fit kernels (CU-masked stream; 0 = no partition)')
     ap.add_argument('--fits-on-reserved-only', type=int, default=1, help='1/0: confine the fit kernels to the reserved CUs (strict partition)')
     ap.add_argument('--aux-cus', type=int, default=0, help='CUs set aside for the pack / histogram stream (multiple of 8; compute kernels are masked off them)')
+    ap.add_argument('--fit-priority', type=int, default=0, help='stream priority of the per-batch (fit) streams: -1 high, 0 normal (default: with equal priorities the dispatcher alternates between the C(t) grid and the fits; 3 %% better than high-priority fits)')
+    ap.add_argument('--main-priority', type=int, default=0, help='stream priority of the main (C(t)) stream')
     ap.add_argument('--fit-waves', type=int, default=0, help='wavefronts per residue in the model-order search (0 = library default)')
     ap.add_argument('--fit-lds', type=int, default=-1, help='1/0: keep residue data in LDS during the fits (-1 = library default)')
     ap.add_argument('--dev-skip-fits', action='store_true', help='DEVELOPMENT ONLY (invalid as a benchmark): leave the fits and the relaxation kernel out, to see the floor the C(t) side alone sets')
     ap.add_argument('--hist-on-main', action='store_true', help='keep the histogram kernel in line with C(t) (only the pack runs beside it)')
     ap.add_argument('--ct-fft', type=int, default=-1, help='kernel 1: 2 = real-input FFT (k_ct_rfft) where it applies, 1 = complex FFT (k_ct_fft), 0 = direct (k_ct_palmer); -1 = library default (2)')
-    ap.add_argument('--depth', type=int, default=6, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
+    ap.add_argument('--depth', type=int, default=5, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true', help='skip the per-kernel alone / saturated timings after the timed region (the `kernels` entries then only carry in-pipeline durations)')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
@@ -254,7 +256,8 @@ def main():
     triples = synth.exact_triples(s['R'], s['F'], V)
     pkw = dict(q_rot=q, Diso=synth.DISO, aniso=aniso, field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA)
     pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], depth=args.depth,
-                          stream=torch.cuda.Stream(device=dev), reserve_cus=args.reserve_cus, aux_cus=args.aux_cus,
+                          stream=torch.cuda.Stream(device=dev, priority=args.main_priority), reserve_cus=args.reserve_cus, aux_cus=args.aux_cus,
+                          fit_priority=args.fit_priority,
                           fits_on_reserved_only=bool(args.fits_on_reserved_only), hist_on_aux=not args.hist_on_main, **pkw)
     stream = pipe.main
     if args.dev_skip_fits:

@@ -118,7 +118,7 @@ class _Slot:
 class DevicePipeline:
     def __init__(self, ctx, device, frames, V, R, F, dt, q_rot=None, Diso=None, aniso=None, field_MHz=(600.133,),
                  zeta=0.890023, histBinX=72, listDoG=(2, 3, 5, 7, 9), csa=None, depth=1, stream=None, reserve_cus=0,
-                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None, hist_on_aux=True, v0=0, aux_cus=0):
+                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None, hist_on_aux=True, v0=0, aux_cus=0, fit_priority=0):
         self.ctx = ctx
         self.dev = device
         self.frames, self.V, self.R, self.F, self.dt = frames, V, R, F, dt
@@ -139,6 +139,7 @@ class DevicePipeline:
         self._owned_streams = []
         resv_words = None
         self.reserve_cus = 0
+        self.fit_priority = int(fit_priority)
         info = ctx.device_info()
         if reserve_cus and self.depth > 1:
             # Mask bit i is CU i/8 of XCD i%8 on MI355X (scripts/dev/cumask.py): a multiple of 8 taken from the top
@@ -241,7 +242,7 @@ class DevicePipeline:
 
     def _fit_stream(self, resv_words):
         if resv_words is None:
-            return torch.cuda.Stream(device=self.dev, priority=-1)
+            return torch.cuda.Stream(device=self.dev, priority=self.fit_priority)
         return self._borrow(resv_words)
 
     def close(self):

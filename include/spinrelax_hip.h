@@ -45,8 +45,8 @@ void         sr_destroy(sr_ctx *);
 int          sr_set_stream(sr_ctx *, void *hip_stream);   /* hipStream_t; NULL = default stream  */
 int          sr_sync(sr_ctx *);
 /* Tuning knobs: "fit_waves" = wavefronts per residue in the fits (1, 2 or 4; default 4: with the chip full of fits
- * all three cost the same per residue -- 0.93 ms per 512-residue benchmark batch -- and 4 has the shortest launch, 9.8
- * against 15.3 and 27.6 ms; results are bit-identical only between runs with the same value), "fit_lds" = 1/0 keep
+ * all three cost the same per residue and 4 has the shortest launch (1.6x and 2.8x shorter than 2 and 1 on the
+ * 512-residue benchmark batch); results are bit-identical only between runs with the same value), "fit_lds" = 1/0 keep
  * a residue's t, C(t), 1/sigma in LDS, "ct_fft" = formulation of kernel 1 where the chunk length allows: 2 (default) the
  * real-input FFT for 4096 < F + L <= 8192 and the complex FFT below, 1 the complex FFT everywhere, 0 always direct. */
 int          sr_set_option(sr_ctx *, const char *name, int value);

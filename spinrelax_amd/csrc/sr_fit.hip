@@ -108,15 +108,15 @@ __device__ __forceinline__ double div_shared_for_exp(double a, double b, double 
 }
 // exp(a / b) for a <= 0 < b with the quotient formed as above: the instruction sequence of the device library's
 // exp() (ROCm 7.2 ocml, read off its ISA: argument reduction by ln2 hi/lo, degree-11 polynomial in Horner form, ldexp)
-// minus what a non-positive argument cannot need -- the overflow select -- and with the underflow select doubling as
-// the guard for huge / infinite quotients (tested on the uncorrected product, which differs from the quotient by two
-// ulp at most: either side of -1075 the result is 0).  Same bits as exp(a / b) wherever that is not 0 or 1 ulp of
-// the threshold (scripts/dev/fit_dump.py: every fit of the fixtures ends on identical parameters); 25 instructions
-// instead of 11 + 23.
+// minus what a non-positive argument cannot need -- the overflow select -- and with one v_max_f64 on the quotient in
+// place of the underflow select (which doubles as the guard for huge / infinite / NaN quotients).  Same bits as
+// exp(a / b) (scripts/dev/fit_dump.py: every fit of the fixtures ends on identical parameters); 23 instructions instead
+// of 11 + 23.
 __device__ __forceinline__ double exp_neg_quotient(double a, double b, double r)
 {
-    const double q0 = a * r;
-    const double q = div_shared(a, b, r);
+    // quotients below -1100 (and the NaN a zero tau makes of the corrected quotient: maxNum returns the other operand)
+    // all end in ldexp(p, <= -1587) = 0, the value exp() has there
+    const double q = fmax(div_shared(a, b, r), -1100.0);
     const double dn = rint(q * 0x1.71547652b82fep+0);
     double t = fma(-0x1.62e42fefa39efp-1, dn, q);
     t = fma(-0x1.abc9e3b39803fp-56, dn, t);
@@ -131,8 +131,7 @@ __device__ __forceinline__ double exp_neg_quotient(double a, double b, double r)
     p = fma(t, p, 0x1.000000000000bp-1);
     p = fma(t, p, 1.0);
     p = fma(t, p, 1.0);
-    const double z = ldexp(p, (int)dn);
-    return q0 >= -1075.0 ? z : 0.0;
+    return ldexp(p, (int)dn);
 }
 
 // ---- model: curvefit_exponential, fitting_Ct_functions.py:419-427 -----------------------------

@@ -90,6 +90,7 @@ def parse():
     ap.add_argument('--aux-cus', type=int, default=0, help='CUs set aside for the pack / histogram stream (multiple of 8; compute kernels are masked off them)')
     ap.add_argument('--fit-priority', type=int, default=0, help='stream priority of the per-batch (fit) streams: -1 high, 0 normal (default: with equal priorities the dispatcher alternates between the C(t) grid and the fits; 3 %% better than high-priority fits)')
     ap.add_argument('--main-priority', type=int, default=0, help='stream priority of the main (C(t)) stream')
+    ap.add_argument('--dev-no-events', action='store_true', help='DEVELOPMENT: no per-kernel HIP events inside the timed region (kernels entries lose their in-pipeline durations)')
     ap.add_argument('--fit-waves', type=int, default=0, help='wavefronts per residue in the model-order search (0 = library default)')
     ap.add_argument('--fit-lds', type=int, default=-1, help='1/0: keep residue data in LDS during the fits (-1 = library default)')
     ap.add_argument('--dev-skip-fits', action='store_true', help='DEVELOPMENT ONLY (invalid as a benchmark): leave the fits and the relaxation kernel out, to see the floor the C(t) side alone sets')
@@ -275,9 +276,11 @@ def main():
         gbuf = {}
 
         def gather_results(slot):
+            """queued right behind a batch (pipeline.run(on_enqueued=...)): waits for the batch on the device, never on the host"""
             if world == 1:
-                return
+                return None
             with torch.cuda.stream(gstream):
+                gstream.wait_event(slot.done)
                 for name in ('Ct', 'dCt', 'hist'):
                     tns = getattr(slot, name)
                     key = (id(slot), name)
@@ -290,10 +293,10 @@ def main():
                 dist.all_gather(gbuf[key], slot.relax)
                 ev = torch.cuda.Event()
                 ev.record(gstream)
-            pipe.main.wait_event(ev)
+            return ev
 
         def run_batches(nb, events=None):
-            pipe.run(vecs, nb, events, on_finished=gather_results)
+            pipe.run(vecs, nb, events, on_enqueued=gather_results)
             torch.cuda.synchronize()
 
         pipe.prime(vecs)                 # set-up (code objects, first touch of every in-flight slot), not a warm-up step
@@ -310,7 +313,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_batches(args.steps, events)
+        run_batches(args.steps, None if args.dev_no_events else events)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -321,9 +324,12 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    ct_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    hist_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in events])) if q is not None else None
-    fit_ms = None if args.dev_skip_fits else float(np.mean([e[4].elapsed_time(e[5]) for e in events]))
+    if args.dev_no_events:
+        ct_ms = hist_ms = fit_ms = float('nan')
+    else:
+        ct_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+        hist_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in events])) if q is not None else None
+        fit_ms = None if args.dev_skip_fits else float(np.mean([e[4].elapsed_time(e[5]) for e in events]))
     best = pipe.fit_best
     nfev_by_order = {str(k): int(np.sum(v)) for k, v in pipe.nfev_last.items()}
     nfits_by_order = {str(k): int(np.size(v)) for k, v in pipe.nfev_last.items()}

@@ -90,6 +90,8 @@ class _Slot:
         self.front_done = None
         self.hist_done = None
         self.done = None
+        self.psum_free = None      # the chunk statistics of the slot's previous batch have consumed its raw sums
+        self.guard = None          # event of a device-side consumer of the slot's result buffers (run(on_enqueued=...))
         self.busy = False
         self.relax_out = None
         self.result = None
@@ -137,6 +139,7 @@ class DevicePipeline:
         self.depth = max(1, int(depth))
         self.main = stream if stream is not None else torch.cuda.current_stream(device)
         self._owned_streams = []
+        self._main_bits = None
         resv_words = None
         self.reserve_cus = 0
         self.fit_priority = int(fit_priority)
@@ -149,6 +152,7 @@ class DevicePipeline:
             r = min(ncu - nx, (int(reserve_cus) + nx - 1) // nx * nx)
             self.reserve_cus = r
             self.main = self._masked_stream(range(ncu - r), ncu)
+            self._main_bits = (range(ncu - r), ncu)
             if fits_on_reserved_only:
                 resv_words = self._mask_words(range(ncu - r, ncu), ncu)
         # Bandwidth kernels on their own few CUs.  The compute kernels (C(t): 249 VGPRs, fits: 256) fill the register file
@@ -164,6 +168,7 @@ class DevicePipeline:
             r = min(ncu - 8, (int(aux_cus) + 7) // 8 * 8)
             self.aux_cus = r
             self.main = self._masked_stream(range(ncu - r), ncu)
+            self._main_bits = (range(ncu - r), ncu)
             resv_words = self._mask_words(range(ncu - r), ncu)          # fits: same complement as the main stream
             aux_words = self._mask_words(range(ncu - r, ncu), ncu)
         Pmax = max(self.listDoG)
@@ -181,6 +186,15 @@ class DevicePipeline:
         self.aux = (self._borrow(aux_words) if aux_words is not None else torch.cuda.Stream(device=device)) if self.depth > 1 else None
         self._packed_ev = [None, None]
         self.hist_on_aux = hist_on_aux
+        # Consecutive C(t) launches alternate between two streams (one per plane buffer): the next grid's workgroups fill the
+        # slots the previous grid's last, partially filled round leaves (a twelfth of a launch) and its launch latency
+        # (~0.15 ms between two 12 288-workgroup kernels on one stream) disappears behind it.
+        self.main_alt = None
+        if self.depth > 1 and hist_on_aux:
+            if self._main_bits is not None:
+                self.main_alt = self._masked_stream(*self._main_bits)
+            else:
+                self.main_alt = torch.cuda.Stream(device=device, priority=getattr(self.main, 'priority', 0))
         # the mean / std over the chunks and the transposes only feed this batch's fits: they run on the batch's own
         # stream, so that the main stream issues the C(t) kernels back to back (4.50 -> 4.41 ms per step)
         self.tail_on_slot_stream = True
@@ -255,12 +269,13 @@ class DevicePipeline:
         self.ctx.device_sync()
         self.ctx.set_stream(0)
         for s in self.slots:
-            s.front_done = s.hist_done = s.done = None
+            s.front_done = s.hist_done = s.done = s.psum_free = s.guard = None
             s.stream = None
             s.release()
         self._packed_ev = [None, None]
         self._ct_done_ev = [None, None]
         self.main = None
+        self.main_alt = None
         self.aux = None
         owned, self._owned_streams = self._owned_streams, []
         for h in owned:
@@ -373,28 +388,51 @@ class DevicePipeline:
                 self._packed_ev[b] = torch.cuda.Event()
                 self._packed_ev[b].record(self.aux)
         self._packed = False
-        self.ctx.set_stream(self.main.cuda_stream)
-        with torch.cuda.stream(self.main):
-            self.main.wait_event(self._packed_ev[b])
+        prev_done = s.done if s.busy else None       # the batch that used this slot `depth` batches ago, if still in flight
+        main = self.main_alt if (b == 1 and self.main_alt is not None and self.tail_on_slot_stream) else self.main
+        self.ctx.set_stream(main.cuda_stream)
+        with torch.cuda.stream(main):
+            main.wait_event(self._packed_ev[b])
+            if s.busy and s.psum_free is not None:
+                main.wait_event(s.psum_free)         # its raw sums are the only thing of that batch this kernel overwrites
             if events is not None:
-                events[0].record(self.main)
+                events[0].record(main)
             self.stage_ct(s, buf, mid_event=None if events is None else events[1], finalize=not self.tail_on_slot_stream)
             if not self.hist_on_aux:
+                if prev_done is not None:
+                    main.wait_event(prev_done)
+                if s.guard is not None:
+                    main.wait_event(s.guard)
                 if events is not None:
-                    events[2].record(self.main)
+                    events[2].record(main)
                 self.stage_hist(s, buf)
                 if events is not None:
-                    events[3].record(self.main)
-            self._ct_done_ev[b] = torch.cuda.Event()            # "the main stream is done with this plane buffer"
-            self._ct_done_ev[b].record(self.main)
+                    events[3].record(main)
+            self._ct_done_ev[b] = torch.cuda.Event()            # "the C(t) kernel is done with this plane buffer"
+            self._ct_done_ev[b].record(main)
             if not self.tail_on_slot_stream:
                 self.stage_transpose(s)
             s.front_done = torch.cuda.Event()
-            s.front_done.record(self.main)
+            s.front_done.record(main)
             s.hist_done = s.front_done
         self.ctx.set_stream(self.aux.cuda_stream)
         with torch.cuda.stream(self.aux):
+            # the pack of batch k+1 first: the next C(t) launch waits for nothing else, while the histogram below may have
+            # to wait for the batch that used this slot before (its relaxation kernel reads the slot's histogram)
+            if pack_next is not None:
+                nb = (k + 1) % 2
+                if self._ct_done_ev[nb] is not None:
+                    self.aux.wait_event(self._ct_done_ev[nb])       # C(t) of batch k-1 has read that buffer (its histogram
+                                                                    # ran earlier on this stream)
+                self.stage_pack(pack_next, self.soa_bufs[nb])
+                self._packed_ev[nb] = torch.cuda.Event()
+                self._packed_ev[nb].record(self.aux)
+                self._packed = True
             if self.hist_on_aux:
+                if prev_done is not None:
+                    self.aux.wait_event(prev_done)
+                if s.guard is not None:
+                    self.aux.wait_event(s.guard)
                 if events is not None:
                     events[2].record(self.aux)
                 self.stage_hist(s, buf)                 # ordered behind the pack of this buffer on the same stream
@@ -402,14 +440,6 @@ class DevicePipeline:
                     events[3].record(self.aux)
                 s.hist_done = torch.cuda.Event()
                 s.hist_done.record(self.aux)
-            if pack_next is not None:
-                nb = (k + 1) % 2
-                if self._ct_done_ev[nb] is not None:
-                    self.aux.wait_event(self._ct_done_ev[nb])       # C(t) of batch k-1 has read that buffer
-                self.stage_pack(pack_next, self.soa_bufs[nb])
-                self._packed_ev[nb] = torch.cuda.Event()
-                self._packed_ev[nb].record(self.aux)
-                self._packed = True
         self.ctx.set_stream(self.main.cuda_stream)
         return s
 
@@ -420,10 +450,15 @@ class DevicePipeline:
         if s.stream is not self.main:
             s.stream.wait_event(s.front_done)
             s.stream.wait_event(s.hist_done)
+            if s.guard is not None:
+                s.stream.wait_event(s.guard)         # a device-side reader of the previous batch's C(t) / table / histogram
+                s.guard = None
         self.ctx.set_stream(s.stream.cuda_stream)
         with torch.cuda.stream(s.stream):
             if self.aux is not None and self.tail_on_slot_stream:
                 self.stage_ct_finalize(s)
+                s.psum_free = torch.cuda.Event()
+                s.psum_free.record(s.stream)
                 self.stage_transpose(s)
             if events is not None and len(events) > 5:
                 events[4].record(s.stream)
@@ -452,17 +487,32 @@ class DevicePipeline:
         self.nfev_last = {nP: r['nfev'][j][tried[j]] for j, nP in enumerate(self.listDoG)}
         return r
 
-    def run(self, vecs, nb, events=None, on_finished=None):
-        """nb batches, up to `depth` in flight.  on_finished(slot) is called for every finished batch, in order."""
+    def run(self, vecs, nb, events=None, on_finished=None, on_enqueued=None):
+        """nb batches, up to `depth` in flight.  on_finished(slot) is called on the host for every finished batch, in order
+        (results collected).  on_enqueued(slot) is called right after a batch's last launch: a consumer that works on the
+        device (e.g. the all-gather of the results) queues itself behind slot.done there and returns an event, which the
+        pipeline waits for before it overwrites that slot's result buffers.  (With batches overlapping, the throughput half
+        of batch k + depth is already queued when on_finished(slot) runs for batch k: the host copies -- slot.result, and
+        C(t) / dC(t) in HBM -- are still batch k's, the slot's histogram in HBM may already be the next batch's.)"""
         D = self.depth
         for k in range(nb):
             s = self.slots[k % D]
+            run_ahead = self.aux is not None and self.tail_on_slot_stream
+            if s.busy and not run_ahead:
+                self.collect(s)
+                if on_finished is not None:
+                    on_finished(s)
+            # Overlapped form: the throughput half of batch k is queued BEFORE the host waits for the batch that used the
+            # slot `depth` batches ago -- C(t) only overwrites that batch's raw sums (free once its chunk statistics ran),
+            # the histogram waits for it on the device -- so the main stream always has its next launch queued.
+            self.front(vecs, k, None if events is None else events[k], pack_next=vecs if k + 1 < nb else None)
             if s.busy:
                 self.collect(s)
                 if on_finished is not None:
                     on_finished(s)
-            self.front(vecs, k, None if events is None else events[k], pack_next=vecs if k + 1 < nb else None)
             self.back(k, None if events is None else events[k])
+            if on_enqueued is not None:
+                s.guard = on_enqueued(s)
         for k in range(max(0, nb - D), nb):
             s = self.slots[k % D]
             if s.busy:

@@ -91,6 +91,7 @@ def parse():
     ap.add_argument('--fit-priority', type=int, default=0, help='stream priority of the per-batch (fit) streams: -1 high, 0 normal (default: with equal priorities the dispatcher alternates between the C(t) grid and the fits; 3 %% better than high-priority fits)')
     ap.add_argument('--main-priority', type=int, default=0, help='stream priority of the main (C(t)) stream')
     ap.add_argument('--dev-no-events', action='store_true', help='DEVELOPMENT: no per-kernel HIP events inside the timed region (kernels entries lose their in-pipeline durations)')
+    ap.add_argument('--plane-buffers', type=int, default=3, help='plane buffers the pack kernel cycles through (2 = the pack of batch k+1 waits for the C(t) launch of batch k-1)')
     ap.add_argument('--fit-waves', type=int, default=0, help='wavefronts per residue in the model-order search (0 = library default)')
     ap.add_argument('--fit-lds', type=int, default=-1, help='1/0: keep residue data in LDS during the fits (-1 = library default)')
     ap.add_argument('--dev-skip-fits', action='store_true', help='DEVELOPMENT ONLY (invalid as a benchmark): leave the fits and the relaxation kernel out, to see the floor the C(t) side alone sets')
@@ -258,7 +259,7 @@ def main():
     pkw = dict(q_rot=q, Diso=synth.DISO, aniso=aniso, field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA)
     pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], depth=args.depth,
                           stream=torch.cuda.Stream(device=dev, priority=args.main_priority), reserve_cus=args.reserve_cus, aux_cus=args.aux_cus,
-                          fit_priority=args.fit_priority,
+                          fit_priority=args.fit_priority, plane_buffers=args.plane_buffers,
                           fits_on_reserved_only=bool(args.fits_on_reserved_only), hist_on_aux=not args.hist_on_main, **pkw)
     stream = pipe.main
     if args.dev_skip_fits:

@@ -120,7 +120,7 @@ class _Slot:
 class DevicePipeline:
     def __init__(self, ctx, device, frames, V, R, F, dt, q_rot=None, Diso=None, aniso=None, field_MHz=(600.133,),
                  zeta=0.890023, histBinX=72, listDoG=(2, 3, 5, 7, 9), csa=None, depth=1, stream=None, reserve_cus=0,
-                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None, hist_on_aux=True, v0=0, aux_cus=0, fit_priority=0):
+                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None, hist_on_aux=True, v0=0, aux_cus=0, fit_priority=0, plane_buffers=3):
         self.ctx = ctx
         self.dev = device
         self.frames, self.V, self.R, self.F, self.dt = frames, V, R, F, dt
@@ -182,9 +182,12 @@ class DevicePipeline:
         # planes: two buffers and an auxiliary stream when batches overlap -- the pack of batch k+1 and the histogram of
         # batch k (bandwidth / FP64 work) run beside the C(t) launch of batch k (FP32 issue bound) instead of in line with it
         self.soa = torch.empty((V, 3, self.Npad), device=device, dtype=torch.float32)
-        self.soa_bufs = [self.soa] + ([torch.empty_like(self.soa)] if self.depth > 1 else [])
+        # (three plane buffers: the pack of batch k+1 only needs the C(t) launch of batch k-2 to be done, so it is off the
+        # critical path of two C(t) launches that overlap each other)
+        self.NB = max(2, int(plane_buffers)) if self.depth > 1 else 1
+        self.soa_bufs = [self.soa] + [torch.empty_like(self.soa) for _ in range(self.NB - 1)]
         self.aux = (self._borrow(aux_words) if aux_words is not None else torch.cuda.Stream(device=device)) if self.depth > 1 else None
-        self._packed_ev = [None, None]
+        self._packed_ev = [None] * self.NB
         self.hist_on_aux = hist_on_aux
         # Consecutive C(t) launches alternate between two streams (one per plane buffer): the next grid's workgroups fill the
         # slots the previous grid's last, partially filled round leaves (a twelfth of a launch) and its launch latency
@@ -198,7 +201,7 @@ class DevicePipeline:
         # the mean / std over the chunks and the transposes only feed this batch's fits: they run on the batch's own
         # stream, so that the main stream issues the C(t) kernels back to back (4.50 -> 4.41 ms per step)
         self.tail_on_slot_stream = True
-        self._ct_done_ev = [None, None]
+        self._ct_done_ev = [None] * self.NB
         t = hostct.calculate_dt(dt, F * dt)
         self.t_host = np.ascontiguousarray(np.broadcast_to(t, (V, self.L)))
         self.t_dev = torch.from_numpy(self.t_host).to(device)
@@ -272,8 +275,8 @@ class DevicePipeline:
             s.front_done = s.hist_done = s.done = s.psum_free = s.guard = None
             s.stream = None
             s.release()
-        self._packed_ev = [None, None]
-        self._ct_done_ev = [None, None]
+        self._packed_ev = [None] * self.NB
+        self._ct_done_ev = [None] * self.NB
         self.main = None
         self.main_alt = None
         self.aux = None
@@ -376,7 +379,7 @@ class DevicePipeline:
                 s.front_done.record(self.main)
                 s.hist_done = s.front_done
             return s
-        b = k % 2
+        b = k % self.NB
         buf = self.soa_bufs[b]
         if not self._packed:
             # first batch of a run: nothing was packed ahead
@@ -389,7 +392,7 @@ class DevicePipeline:
                 self._packed_ev[b].record(self.aux)
         self._packed = False
         prev_done = s.done if s.busy else None       # the batch that used this slot `depth` batches ago, if still in flight
-        main = self.main_alt if (b == 1 and self.main_alt is not None and self.tail_on_slot_stream) else self.main
+        main = self.main_alt if (k % 2 == 1 and self.main_alt is not None and self.tail_on_slot_stream) else self.main
         self.ctx.set_stream(main.cuda_stream)
         with torch.cuda.stream(main):
             main.wait_event(self._packed_ev[b])
@@ -420,9 +423,9 @@ class DevicePipeline:
             # the pack of batch k+1 first: the next C(t) launch waits for nothing else, while the histogram below may have
             # to wait for the batch that used this slot before (its relaxation kernel reads the slot's histogram)
             if pack_next is not None:
-                nb = (k + 1) % 2
+                nb = (k + 1) % self.NB
                 if self._ct_done_ev[nb] is not None:
-                    self.aux.wait_event(self._ct_done_ev[nb])       # C(t) of batch k-1 has read that buffer (its histogram
+                    self.aux.wait_event(self._ct_done_ev[nb])       # C(t) of batch k+1-NB has read that buffer (its histogram
                                                                     # ran earlier on this stream)
                 self.stage_pack(pack_next, self.soa_bufs[nb])
                 self._packed_ev[nb] = torch.cuda.Event()

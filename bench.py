@@ -512,6 +512,18 @@ def main():
                                                   'credited to the duration of the kernel that computes C(t)',
                                           'kernel': kname, 'kernel_ms': ct_ms, 'TFLOPs_equiv': 8.0 * triples / (ct_ms * 1e-3) / 1e12,
                                           'streaming_equiv_GBps': 24.0 * triples / (ct_ms * 1e-3) / 1e9}}
+        # what the whole chip does per step: executed float64 work of every kernel of a batch over the step time (the
+        # per-kernel `frac` of an overlapped pipeline is diluted by sharing: two C(t) launches, the fits of three batches, the
+        # pack and the histogram run at the same time, so a launch's own duration says little about the chip)
+        prof_all, _ = committed_profile()
+        step_flop = sum(float(v.get('fp64_flop_per_launch') or 0.0) * (2 if k.startswith('k_transpose') else 1) for k, v in prof_all.items()
+                        if not k.startswith('k_fft_init'))
+        roofline['frac_alone'] = tk.get('frac_alone')
+        roofline['launches_of_this_kernel_in_flight'] = (tk.get('in_pipeline_ms') or 0.0) / ms_per_step if ms_per_step else None
+        roofline['chip'] = None if not (cfg == 3 and V == 512 and step_flop > 0) else {'fp64_flop_per_step': step_flop, 'TFLOPs': step_flop / (ms_per_step * 1e-3) / 1e12,
+                            'frac': step_flop / (ms_per_step * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+                            'note': 'executed float64 flop of all kernels of a batch (committed PMC pass) over ms_per_step: the fraction of '
+                                    'the FP64 vector peak the pipeline as a whole sustains'}
         res = {
             'metric': 'frame-vector-lag triples/s, C(t) + fit + R1/R2/NOE pipeline',
             'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -895,7 +895,12 @@ __device__ __forceinline__ void rfft_workgroup(cplx *v, cplx *w, cplx *lds, cplx
 #pragma unroll
         for (int p = 0; p < 16; ++p) bw[17 * bitrev<4>(p)] = u[p];
     }
-    __syncthreads();
+    // The row thread tid reads next (17 tid .. 17 tid + 15) was written by the 16 threads (k1, lo = 0..15) = 16 k1 .. 16 k1 + 15:
+    // its own 16-lane group.  LDS operations of one wave complete in order, so no workgroup barrier is needed here -- only
+    // the compiler must not move the reads above the writes.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (act) {
         const cplx *b = lds + 17 * tid;
 #pragma unroll

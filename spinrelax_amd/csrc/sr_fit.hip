@@ -59,6 +59,9 @@ __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 //                            every measure once the reductions below were out of the way (6.69 / 0.728 against 6.84 / 0.746).
 //   SR_FIT_REDUCE_MANY=1 (default) the 54 lane sums of a Jacobian by the register-halving reduction of sr_internal.h
 //                            (different association: the fits move in their last bits): 8.95 -> 6.85 / 0.832 -> 0.745
+// Tried and dropped (bit-identical): evaluating trial points with a fused model + Jacobian pass (an accepted step then needs
+// no second pass: the exponentials of the model once per evaluation instead of twice): 0.716 -> 0.692 ms saturated but
+// 6.58 -> 6.79 ms alone (the slowest residue rejects many trial steps, each now paying for a Jacobian; scratch 872 -> 1 192 B).
 // Round 1 had tried Markstein with the reciprocals in VGPRs and a branch for huge quotients: the kernel lives at the
 // 256-register limit of two waves per SIMD, the extra live values spilled inside the Jacobian loop and the branch kept
 // the scheduler from interleaving the independent exponentials of a point (12.7 -> 16.8 ms).  Uniform values in SGPRs

@@ -92,3 +92,37 @@ def test_script_from_raw_coordinates_to_Ct(ctx, tmp_path):
     legs, t, Cx, dCx = gs.load_sxydylist(out + '_Ctext.dat', 'legend')
     Cl, _ = o.calculate_Ct_Palmer(o.reformat_vecs_by_tau([lab], s['dt'], s['tau_memory']))
     assert np.max(np.abs(np.array(Cx).T / Cl - 1)) < 1e-6
+
+
+def test_round2_entry_points_refuse_bad_arguments(ctx):
+    """Shapes and index ranges are checked on the host before anything is launched (a kernel fed an out-of-range atom
+    index or lag would fault): every refusal is a SpinRelaxHipError carrying the library's message."""
+    from spinrelax_amd.hip import SpinRelaxHipError
+    d = synth.synth_coordinates(8, 4, 5)
+    with pytest.raises(SpinRelaxHipError, match='out of range'):
+        ctx.xh_vectors(d['xyz'], np.array([0, 2, 4, 99999], dtype=np.int32), d['indexH'])
+    with pytest.raises(SpinRelaxHipError, match='fit atom'):
+        ctx.xh_vectors(d['xyz'], d['indexX'], d['indexH'], fit_indices=np.array([0, 1, 10 ** 6], dtype=np.int32), ref_xyz=d['ref_xyz'])
+    with pytest.raises(SpinRelaxHipError, match='3 fit atoms'):
+        ctx.xh_vectors(d['xyz'], d['indexX'], d['indexH'], fit_indices=np.array([0, 1], dtype=np.int32), ref_xyz=d['ref_xyz'])
+    with pytest.raises(ValueError):
+        ctx.xh_vectors(d['xyz'][..., :2], d['indexX'], d['indexH'])
+    q = synth.synth_orientation(50, 3)
+    with pytest.raises(SpinRelaxHipError, match='out of range'):
+        ctx.dq_moments(q, [1, 50])                      # a lag must leave at least one pair
+    with pytest.raises(SpinRelaxHipError, match='out of range'):
+        ctx.dq_moments(q, [0])
+    with pytest.raises(ValueError):
+        ctx.dq_moments(q[:, :3], [1])
+    # rsCSA search: per-experiment arrays must match, the column code must be 0 / 1 / 2
+    st = np.ones((2, 3, 12))
+    ok = dict(stats=st, column=[0, 1], csa_prefactor=[1.0, 1.0], noe_factor=[1.0, 1.0], f_DD=[1.0, 1.0], target=np.ones((2, 3)),
+              dtarget=np.zeros((2, 3)), cover=np.ones((2, 3), dtype=np.uint8), has_err=True, csa0=np.full(3, 1e-4), step=1e-5)
+    csa, vals, errs, fopt, nfev = ctx.rscsa_search(**ok)
+    assert csa.shape == (3,) and np.all(nfev > 0) and np.all(np.isfinite(vals))
+    with pytest.raises(SpinRelaxHipError, match='column'):
+        ctx.rscsa_search(**dict(ok, column=[0, 3]))
+    with pytest.raises(ValueError):
+        ctx.rscsa_search(**dict(ok, target=np.ones((2, 4))))
+    with pytest.raises(ValueError):
+        ctx.rscsa_search(**dict(ok, stats=np.ones((2, 3, 11))))

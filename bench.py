@@ -83,6 +83,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100, help='timed batches (the pipeline keeps --depth of them in flight; its fill and drain are inside the timed region)')
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--repeats', type=int, default=3, help='the timed region (exactly --steps steps between two synchronisations) is run this many times; value / ms_per_step are the MEDIAN, every sample is listed')
+    ap.add_argument('--spinup-s', type=float, default=1.0, help='untimed seconds of the same pipeline before the warm-up steps: a fresh box needs about a second under load before the clocks settle (5 warm-up steps are 15 ms)')
+    ap.add_argument('--steady-steps', type=int, default=120, help='steps of the extra (untimed for the headline) long run behind ms_per_step_steady; 0 = skip')
     ap.add_argument('--workload', type=str, default='cfg3', choices=['cfg2', 'cfg3'])
     ap.add_argument('--vectors', type=int, default=None, help='vectors per GPU (default: the config value)')
     ap.add_argument('--reserve-cus', type=int, default=0, help='CUs kept free of the C(t)/histogram kernels for the latency-bound fit kernels (CU-masked stream; 0 = no partition)')
@@ -203,12 +206,13 @@ def fft_exec_flop(s, V, real_input=False):
     k_ct_fft: 4 complex M-point transforms (5 M log2 M flop each), the power spectra of 3 packed pairs (12 flop per
     frequency each) and the 6 products per frame, per (chunk, vector).  k_ct_rfft: 7 complex transforms of H = M/2 points,
     two twiddle passes (6 flop per point) per transform and the real-signal spectrum step (24 flop per frequency) for the
-    six signals."""
+    six signals (five in the traceless form of k_ct_rfft<12>: 6 transforms in all)."""
     need = s['F'] + s['L']
     M = 2048 if need <= 2048 else (4096 if need <= 4096 else (6144 if need <= 6144 else 8192))
     if real_input:
         H = M // 2
-        return M, s['R'] * V * (7 * (5 * H * np.log2(H) + 12 * H) + 6 * 24 * H + 6 * s['F'])
+        nf = 5 if M == 6144 else 6          # traceless form (5 forward transforms) where the chunk allows it (k_ct_rfft<12>)
+        return M, s['R'] * V * ((nf + 1) * (5 * H * np.log2(H) + 12 * H) + nf * 24 * H + 6 * s['F'])
     return M, s['R'] * V * (4 * 5 * M * np.log2(M) + 3 * 12 * M + 6 * s['F'])
 
 
@@ -306,25 +310,44 @@ def main():
                 gather_results(sl)
             torch.cuda.synchronize()
             dist.barrier()
+        # clock spin-up (untimed, same work as the timed steps): run until --spinup-s seconds have passed
+        spin_steps, t_spin = 0, time.perf_counter()
+        while time.perf_counter() - t_spin < args.spinup_s:
+            run_batches(10)
+            spin_steps += 10
+        spin_s = time.perf_counter() - t_spin
         run_batches(args.warmup)
         nfev0 = pipe.nfev_total
-        events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_batches(args.steps, None if args.dev_no_events else events)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        samples = []
+        events = None
+        for rep in range(max(1, args.repeats)):
+            events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_batches(args.steps, None if args.dev_no_events else events)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            samples.append(time.perf_counter() - t0)
+        nfev_timed = pipe.nfev_total - nfev0
+        # steady state: one long run, fill and drain amortised (reported beside the headline, never as it)
+        steady = None
+        if args.steady_steps > 0:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_batches(args.steady_steps)
+            steady = (time.perf_counter() - t0) / args.steady_steps
 
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:                  # every repeat: the slowest rank's time
+        tmax = torch.tensor(samples + [steady or 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        samples = [float(x) for x in tmax[:-1].tolist()]
+        steady = float(tmax[-1].item()) if steady else None
+    elapsed = float(np.median(samples))
     if args.dev_no_events:
         ct_ms = hist_ms = fit_ms = float('nan')
     else:
@@ -334,7 +357,7 @@ def main():
     best = pipe.fit_best
     nfev_by_order = {str(k): int(np.sum(v)) for k, v in pipe.nfev_last.items()}
     nfits_by_order = {str(k): int(np.size(v)) for k, v in pipe.nfev_last.items()}
-    nfev_step = (pipe.nfev_total - nfev0) / max(1, args.steps)
+    nfev_step = nfev_timed / max(1, args.steps * max(1, args.repeats))
     depth_used, reserve_used = pipe.depth, pipe.reserve_cus
     listDoG = pipe.listDoG
     del events, gbuf
@@ -373,7 +396,6 @@ def main():
         alone['ct_finalize'] = timed(lambda: p1.stage_ct_finalize(s0))
         if q is not None:
             alone['hist'] = timed(lambda: p1.stage_hist(s0))
-        alone['transpose'] = timed(lambda: p1.stage_transpose(s0))
         alone['fit'] = timed(lambda: p1.stage_fit(s0), reps=2)
         alone['relax'] = timed(lambda: p1.stage_relax(s0))
         # the direct formulation of kernel 1 (the north-star's named kernel) as a second line
@@ -457,7 +479,8 @@ def main():
             xsrc = 'formula (bench.py:fft_exec_flop)'
             if pe and pe.get('fp64_flop_per_launch'):
                 xflop, xsrc = pe['fp64_flop_per_launch'], 'PMC float64 instruction counts of the committed profile %s' % prof_src
-            form = ('Wiener-Khinchin on real input: 6 + 1 float64 complex transforms of %d points (half the padded length), two workgroups per CU' % (M // 2)
+            form = ('Wiener-Khinchin on real input: %s float64 complex transforms of %d points (half the padded length), two workgroups per CU'
+                    % ('5 (traceless components; the trace term from prefix sums) + 1' if M == 6144 else '6 + 1', M // 2)
                     if use_rfft else 'Wiener-Khinchin: 6 float64 autocorrelations by FFT, whole %d-point transform resident in LDS' % M)
             entry(kname, 'valu-fp64 (float64 vector FMA; latency- and LDS-exchange-limited)', xflop, 1e12, PEAK_FP64_TFLOPS, 'TFLOP/s',
                   ct_ms, alone.get('ct'), formulation=form, work_source=xsrc,
@@ -527,7 +550,13 @@ def main():
         res = {
             'metric': 'frame-vector-lag triples/s, C(t) + fit + R1/R2/NOE pipeline',
             'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'latency_ms': latency, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': ms_per_step, 'timed_region_samples_ms_per_step': [x / args.steps * 1e3 for x in samples],
+            'timed_region_note': 'the timed region (exactly %d steps between two synchronisations, fill and drain inside) was run %d times; '
+                                 'value and ms_per_step are the median' % (args.steps, len(samples)),
+            'ms_per_step_steady': None if steady is None else steady * 1e3,
+            'steady_note': 'one run of %d steps, fill and drain amortised; not the headline' % args.steady_steps,
+            'spinup': {'seconds': spin_s, 'steps': spin_steps, 'note': 'untimed steps of the same pipeline before the warm-up steps (clock ramp of a fresh box)'},
+            'latency_ms': latency, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64 (C(t) by FFT on f32 inputs; histogram, fit, J(w), R1/R2/NOE)' if use_fft else 'f32 dot products / f64 accumulation (C(t)); f64 (histogram, fit, J(w), R1/R2/NOE)',
             'data': 'synthetic',
             'config': {'workload': 'BASELINE cfg%d per GPU: %d frames x %d vectors, %d chunks x %d frames, %d lags, '

@@ -115,6 +115,10 @@ int64_t sr_ct_max_frames_per_chunk(sr_ctx *);
 int sr_ct_palmer_sums_f32_dev(sr_ctx *, const float *soa, int64_t Npad, int64_t R, int64_t F, int64_t nV,
                               const int64_t *chunk_start_host, int mode, double *psum);
 int sr_ct_finalize_f64_dev(sr_ctx *, const double *psum, int64_t R, int64_t F, int64_t nV, double *Ct, double *dCt);
+/* the same launch also leaves the transposed copies CtT, dCtT (nV, L) the fits read (fitting_Ct_functions.py:149 works
+ * per residue); both NULL = not wanted. */
+int sr_ct_finalize_t_f64_dev(sr_ctx *, const double *psum, int64_t R, int64_t F, int64_t nV, double *Ct, double *dCt,
+                             double *CtT, double *dCtT);
 int sr_ct_palmer_f32_dev(sr_ctx *, const float *soa, int64_t Npad, int64_t R, int64_t F, int64_t nV,
                          const int64_t *chunk_start_host, int mode,
                          double *psum_ws, double *Ct, double *dCt);

@@ -46,6 +46,7 @@ SIGNATURES = {
     'sr_ct_max_frames_per_chunk': (c_int64, [c_void_p]),
     'sr_ct_palmer_sums_f32_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p]),
     'sr_ct_finalize_f64_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    'sr_ct_finalize_t_f64_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'sr_ct_palmer_f32_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int,
                                      c_void_p, c_void_p, c_void_p]),
     'sr_ct_palmer_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,

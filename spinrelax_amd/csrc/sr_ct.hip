@@ -910,14 +910,37 @@ __device__ __forceinline__ void rfft_workgroup(cplx *v, cplx *w, cplx *lds, cplx
 }
 
 // HALF: the chunk fills at most 2/3 (N1 = 12) or 1/2 (N1 = 16) of the padded length: the thread's inputs beyond NZ are
-// known to be zero and are neither loaded nor multiplied
-template <int N1, bool HALF>
+// known to be zero and are neither loaded nor multiplied.
+//
+// TR ("traceless"): FIVE forward transforms instead of six.  With T = u (x) u and s = |u|^2,
+//     (u.u')^2 = sum_ij T_ij T'_ij = sum_ij Q_ij Q'_ij + s s' / 3,        Q = T - (s/3) 1   (traceless, 5 components),
+//     sum_ij Q_ij Q'_ij = d1 d1'/2 + d2 d2'/6 + 2 (xy x'y' + xz x'z' + yz y'z'),  d1 = x^2 - y^2,  d2 = 2 z^2 - x^2 - y^2
+// (an orthonormal change of basis on the diagonal (x^2, y^2, z^2); exact for ANY vectors).  The bond vectors are unit
+// vectors rounded to float32: s = 1 + e with |e| < 3e-7, so the trace term needs no transform,
+//     sum_{j < F-d} s_j s_{j+d} = (F - d) + P[F-d] + (P[F] - P[d]) + O(F e^2),      P[k] = sum_{j<k} e_j  (prefix sums),
+// and the neglected O(e^2) part is < 1e-13 of C(t).  The prologue computes e for every frame of the series (it holds x, y, z
+// for the first signal anyway), the workgroup scans it once, and P stays in LDS as float32 (16 KB) until the lags are
+// written.  A series with any |e| >= kUnitTol (not a unit vector: zero vectors from the 0/0 guard of vecnorm_NDarray,
+// callers with unnormalised input) runs the sixth transform on s instead -- decided per workgroup, same kernel.
+constexpr double kUnitTol = 5e-7;
+
+template <bool TR> __device__ __forceinline__ int rfft_plane_a(int c) { return TR ? (c == 4 ? 1 : 0) : (c < 3 ? c : (c == 5 ? 1 : 0)); }
+template <bool TR> __device__ __forceinline__ int rfft_plane_b(int c) { return TR ? (c == 3 || c == 4 ? 2 : 1) : (c < 3 ? c : (c == 3 ? 1 : 2)); }
+// weight / 4 of signal c in the power spectrum
+template <bool TR> __device__ __forceinline__ double rfft_weight4(int c)
+{
+    if (!TR) return c < 3 ? 0.25 : 0.5;
+    return c == 0 ? 1.0 / 24.0 : (c == 1 ? 0.125 : (c == 5 ? 1.0 / 12.0 : 0.5));
+}
+
+template <int N1, bool HALF, bool TR>
 __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
 {
     extern __shared__ __align__(16) unsigned char fft_smem[];
     cplx *lds = reinterpret_cast<cplx *>(fft_smem);
     constexpr int H = N1 * 256, M = 2 * H;
     constexpr int NZ = HALF ? (N1 == 12 ? 8 : N1 / 2) : N1;
+    float *Pl = reinterpret_cast<float *>(lds + rfft_lds_slots(N1) + 256);     // TR: prefix sums P[0 .. 512 NZ], then 8 floats
     const int tid0 = threadIdx.x;
     const int v = blockIdx.x / a.R, r = blockIdx.x - v * a.R;
     const int F = a.F;
@@ -938,6 +961,37 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
     double Wk[8], Wm[8], Wmid = 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) Wk[q] = Wm[q] = 0.0;
+
+    // signal c is a product of two of the three planes (TR: c = 1 is x^2 - y^2; c = 0 and 5 need all three, see below).
+    // Thread t holds the pairs of frames (2m, 2m + 1), m = t + 256 n1; unconditional range-checked loads (no branch per
+    // sample), one 8-byte load per plane when the pair is aligned.  The loads of signal c + 2 are issued right after the
+    // samples of signal c + 1 have been turned into its input, i.e. a whole transform before they are needed (15 % of the
+    // kernel was spent waiting for them at the top of every transform).
+    // Loads go through buffer resources that cover exactly the chunk's F frames of a plane: a frame past the chunk reads
+    // as 0 by the hardware range check -- no clamp, no select, and the address is one 32-bit byte offset per load instead
+    // of a 64-bit add (13 % of the transform loop's instructions were address arithmetic and masks).
+    float2 ar[NZ], br[NZ];
+#define SR_RFFT_LOAD1(DST, PLANE, T)                                                             \
+    {                                                                                            \
+        const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                    \
+            const_cast<float *>(px + (int64_t)(PLANE) * a.Npad), (short)0, F * 4, 0x00020000);   \
+        if (even) {                                                                              \
+            _Pragma("unroll") for (int n1 = 0; n1 < NZ; ++n1)                                    \
+                DST[n1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_, 8 * ((T) + 256 * n1), 0, 0)); \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int n1 = 0; n1 < NZ; ++n1) {                                  \
+                const int ob_ = 8 * ((T) + 256 * n1);                                            \
+                DST[n1] = make_float2(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, ob_, 0, 0)),      \
+                                      __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, ob_ + 4, 0, 0))); \
+            }                                                                                    \
+        }                                                                                        \
+    }
+#define SR_RFFT_LOAD(C, T)                                                                       \
+    {                                                                                            \
+        const int cc_ = (C);                                                                     \
+        SR_RFFT_LOAD1(ar, rfft_plane_a<TR>(cc_), T)                                              \
+        SR_RFFT_LOAD1(br, rfft_plane_b<TR>(cc_), T)                                              \
+    }
     {
         // step-2 twiddles w_256^(lo k2a), transposed so that the 16 lanes of a ds_read_b128 group (consecutive lo) hit 16
         // consecutive slots; ordered before their first use by the first barrier of the first transform
@@ -945,58 +999,93 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
         lds[rfft_lds_slots(N1) + tid0] = cplx{a.tab[2 * (256 + j)], a.tab[2 * (256 + j) + 1]};
     }
 
-    // signal c = x^2, y^2, z^2, xy, xz, yz: product of two of the three planes.  Thread t holds the pairs of frames
-    // (2m, 2m + 1), m = t + 256 n1; unconditional range-checked loads (no branch per sample), one 8-byte load per plane
-    // when the pair is aligned.  The loads of signal c + 1 are issued before the transform of signal c (15 % of the
-    // kernel was spent waiting for them at the top of every transform).
-    // Loads go through buffer resources that cover exactly the chunk's F frames of a plane: a frame past the chunk reads
-    // as 0 by the hardware range check -- no clamp, no select, and the address is one 32-bit byte offset per load instead
-    // of a 64-bit add (13 % of the transform loop's instructions were address arithmetic and masks).
-    float2 ar[NZ], br[NZ];
-#define SR_RFFT_LOAD(C, T)                                                                       \
-    {                                                                                            \
-        const int cc_ = (C);                                                                     \
-        const int ia_ = cc_ < 3 ? cc_ : (cc_ == 5 ? 1 : 0), ib_ = cc_ < 3 ? cc_ : (cc_ == 3 ? 1 : 2); \
-        const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(                    \
-            const_cast<float *>(px + (int64_t)ia_ * a.Npad), (short)0, F * 4, 0x00020000);       \
-        const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(                    \
-            const_cast<float *>(px + (int64_t)ib_ * a.Npad), (short)0, F * 4, 0x00020000);       \
-        _Pragma("unroll") for (int n1 = 0; n1 < NZ; ++n1) {                                      \
-            const int ob_ = 8 * ((T) + 256 * n1);                                                \
-            if (even) {                                                                          \
-                ar[n1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(ra_, ob_, 0, 0)); \
-                br[n1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rb_, ob_, 0, 0)); \
-            } else {                                                                             \
-                ar[n1] = make_float2(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra_, ob_, 0, 0)),      \
-                                     __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra_, ob_ + 4, 0, 0)));  \
-                br[n1] = make_float2(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_, ob_, 0, 0)),      \
-                                     __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_, ob_ + 4, 0, 0)));  \
-            }                                                                                    \
-        }                                                                                        \
+    cplx sig[N1];                 // input of the next transform (entries >= NZ stay zero)
+#pragma unroll
+    for (int n1 = 0; n1 < N1; ++n1) sig[n1] = cplx{0.0, 0.0};
+    int nsig = 6;
+    if (TR) {
+        // ---- prologue of the traceless form: signal 0 = 2 z^2 - x^2 - y^2, e = |u|^2 - 1 and its prefix sums ----
+        double e1[NZ], e2[NZ], emax = 0.0;
+        {
+            float2 zr[NZ];
+            SR_RFFT_LOAD(0, tid0)                      // x, y
+            SR_RFFT_LOAD1(zr, 2, tid0)
+#pragma unroll
+            for (int n1 = 0; n1 < NZ; ++n1) {
+                const double x0 = (double)ar[n1].x, x1 = (double)ar[n1].y, y0 = (double)br[n1].x, y1 = (double)br[n1].y;
+                const double z0 = (double)zr[n1].x, z1 = (double)zr[n1].y;
+                const double q0 = fma(x0, x0, y0 * y0), q1 = fma(x1, x1, y1 * y1), zz0 = z0 * z0, zz1 = z1 * z1;
+                sig[n1] = cplx{(zz0 + zz0) - q0, (zz1 + zz1) - q1};
+                const int f0 = 2 * (tid0 + 256 * n1);
+                const double ea = f0 < F ? (q0 + zz0) - 1.0 : 0.0, eb = f0 + 1 < F ? (q1 + zz1) - 1.0 : 0.0;
+                e1[n1] = eb;
+                e2[n1] = ea + eb;
+                emax = fmax(emax, fmax(fabs(ea), fabs(eb)));
+            }
+        }
+        SR_RFFT_LOAD(1, tid0)
+        // scan scratch in the (still unused) transform image: S[n1][t] pair sums, then block totals and wave maxima behind P
+        double *S = reinterpret_cast<double *>(lds);
+        float *aux = Pl + 512 * NZ + 8;                 // 8 doubles: block totals; then floats [16 .. 20): wave maxima of |e|
+#pragma unroll
+        for (int n1 = 0; n1 < NZ; ++n1) S[n1 * 256 + tid0] = e2[n1];
+        {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) emax = fmax(emax, __shfl_xor(emax, m, 64));
+            if ((tid0 & 63) == 0) aux[16 + (tid0 >> 6)] = (float)emax;     // float32: only compared with the tolerance
+        }
+        __syncthreads();
+        {
+            // wave w scans the blocks n1 = w, w + 4, ...: lane l owns the pair sums 4 l .. 4 l + 3 of the block
+            const int lane = tid0 & 63, wave = tid0 >> 6;
+            for (int n1 = wave; n1 < NZ; n1 += 4) {
+                double *Sb = S + n1 * 256 + 4 * lane;
+                const double a0 = Sb[0], a1 = a0 + Sb[1], a2 = a1 + Sb[2], a3 = a2 + Sb[3];
+                double inc = a3;
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) {
+                    const double o = __shfl_up(inc, m, 64);
+                    if (lane >= m) inc += o;
+                }
+                const double exc = inc - a3;
+                Sb[0] = exc + a0; Sb[1] = exc + a1; Sb[2] = exc + a2; Sb[3] = exc + a3;
+                if (lane == 63) reinterpret_cast<double *>(aux)[n1] = inc;      // block total
+            }
+        }
+        __syncthreads();
+        {
+            const double *tot = reinterpret_cast<const double *>(aux);
+            double off = 0.0;
+#pragma unroll
+            for (int n1 = 0; n1 < NZ; ++n1) {
+                const double inc = S[n1 * 256 + tid0] + off;             // prefix through frame 2 m + 1, m = tid0 + 256 n1
+                const int m = tid0 + 256 * n1;
+                Pl[2 * m + 1] = (float)(inc - e1[n1]);
+                Pl[2 * m + 2] = (float)inc;
+                off += tot[n1];
+            }
+            if (tid0 == 0) Pl[0] = 0.f;
+            const float mx = fmaxf(fmaxf(aux[16], aux[17]), fmaxf(aux[18], aux[19]));
+            nsig = __builtin_amdgcn_readfirstlane(mx < (float)kUnitTol ? 5 : 6);
+        }
+        __syncthreads();                                // S is read: the first transform may overwrite the image
+    } else {
+        SR_RFFT_LOAD(0, tid0)
+#pragma unroll
+        for (int n1 = 0; n1 < NZ; ++n1)
+            sig[n1] = cplx{(double)ar[n1].x * (double)br[n1].x, (double)ar[n1].y * (double)br[n1].y};
+        SR_RFFT_LOAD(1, tid0)
     }
-    SR_RFFT_LOAD(0, tid0)
 #pragma unroll 1
-    for (int c = 0; c < 6; ++c) {
+    for (int c = 0; c < nsig; ++c) {
         asm volatile("" ::: "memory");
         const int tid = opaque(tid0);
         const int k1 = tid >> 4, k2a = tid & 15;
         const bool act = k1 < N1;
         const int pt = k1 != 0 ? (N1 - k1) * 16 + (15 - k2a) : (k2a != 0 ? 16 - k2a : 0);
         const int off0 = tid == 0 ? 1 : 0;
-        // the samples of this signal were loaded while the previous transform ran (before the loop for the first one)
-        cplx sig[N1];
-#pragma unroll
-        for (int n1 = 0; n1 < N1; ++n1) {
-            if (n1 >= NZ) {
-                sig[n1] = cplx{0.0, 0.0};
-                continue;
-            }
-            sig[n1] = cplx{(double)ar[n1].x * (double)br[n1].x, (double)ar[n1].y * (double)br[n1].y};
-        }
-        // step-1 twiddle base w_H^tid: loaded BEFORE the prefetch so that waiting for it (vmcnt counts in order) leaves the
-        // prefetched samples in flight
+        // step-1 twiddle base w_H^tid
         const cplx base1 = opaque(cplx{a.tab[2 * tid], a.tab[2 * tid + 1]});
-        if (c < 5) SR_RFFT_LOAD(c + 1, tid)
         cplx w[16];
         rfft_workgroup<N1>(sig, w, lds, base1, tid);
         // own row again, now in frequency order k2b; then every thread reads the partner frequencies of its 8 pairs
@@ -1007,7 +1096,7 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
         }
         __syncthreads();
         if (act) {
-            const double wgt = c < 3 ? 0.25 : 0.5;                // weight / 4
+            const double wgt = rfft_weight4<TR>(c);               // weight / 4
             const cplx *b = lds + 17 * pt + off0;
             const cplx wb = opaque(wbase);
 #pragma unroll
@@ -1033,6 +1122,43 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
                 const cplx T = cmul(mul_w32_rt(wb, 8), D);
                 const double pr = S.re + T.im, pi = S.im - T.re;
                 Wmid = fma(wgt, fma(pr, pr, pi * pi), Wmid);
+            }
+        }
+        // the next signal's input from the samples loaded one transform ago (w is dead here: few live registers), and the loads
+        // of the one after it.  Unconditional (behind the last signal the values are simply not used): a conditional
+        // assignment would keep the transform's in-place leftovers in `sig` alive through the spectrum step.
+        {
+            const int cn = c + 1;
+            const bool dsq = TR && cn == 1;                        // x^2 - y^2 = (x - y)(x + y)
+            // keep these products HERE: nothing ties them to this point but their inputs, and scheduled above the spectrum
+            // step (where w[16] is live) they push the accumulators into scratch
+#pragma unroll
+            for (int n1 = 0; n1 < NZ; ++n1)
+                asm volatile("" : "+v"(ar[n1].x), "+v"(ar[n1].y), "+v"(br[n1].x), "+v"(br[n1].y));
+#pragma unroll
+            for (int n1 = 0; n1 < N1; ++n1) {
+                if (n1 >= NZ) {
+                    sig[n1] = cplx{0.0, 0.0};
+                    continue;
+                }
+                const double a0 = (double)ar[n1].x, a1 = (double)ar[n1].y, b0 = (double)br[n1].x, b1 = (double)br[n1].y;
+                const double A0 = dsq ? a0 - b0 : a0, A1 = dsq ? a1 - b1 : a1, B0 = dsq ? a0 + b0 : b0, B1 = dsq ? a1 + b1 : b1;
+                sig[n1] = cplx{A0 * B0, A1 * B1};
+            }
+            if (TR && cn == 5 && nsig == 6) {          // not a unit vector: s = x^2 + y^2 + z^2 itself (rare; the z load is exposed)
+#pragma unroll
+                for (int n1 = 0; n1 < NZ; ++n1) {
+                    const double a0 = (double)ar[n1].x, a1 = (double)ar[n1].y, b0 = (double)br[n1].x, b1 = (double)br[n1].y;
+                    sig[n1] = cplx{fma(a0, a0, b0 * b0), fma(a1, a1, b1 * b1)};
+                }
+                SR_RFFT_LOAD1(ar, 2, tid)
+#pragma unroll
+                for (int n1 = 0; n1 < NZ; ++n1) {
+                    const double z0 = (double)ar[n1].x, z1 = (double)ar[n1].y;
+                    sig[n1] = cplx{fma(z0, z0, sig[n1].re), fma(z1, z1, sig[n1].im)};
+                }
+            } else if (c + 2 < nsig) {
+                SR_RFFT_LOAD(c + 2, tid)
             }
         }
         __syncthreads();
@@ -1061,68 +1187,135 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
     }
     __syncthreads();
     {
-        cplx sig[N1];
+        cplx yin[N1];
 #pragma unroll
         for (int n1 = 0; n1 < N1; ++n1) {
             const int k = tid + 256 * n1;
-            sig[n1] = lds[k + k / N1];
+            yin[n1] = lds[k + k / N1];
         }
         __syncthreads();
         cplx w[16];
-        rfft_workgroup<N1>(sig, w, lds, opaque(cplx{a.tab[2 * tid], a.tab[2 * tid + 1]}), tid);
+        rfft_workgroup<N1>(yin, w, lds, opaque(cplx{a.tab[2 * tid], a.tab[2 * tid + 1]}), tid);
         if (act) {
             double *out = a.psum + ((int64_t)v * a.R + r) * a.Lp;
             const double inv = 1.0 / (double)M;
+            const bool unit = TR && nsig == 5;
+            const double PF = unit ? (double)Pl[F] : 0.0;
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
                 const int m = k1 + N1 * (k2a + 16 * bitrev<4>(p));
                 const int le = 2 * m, lod = 2 * m - 1;
-                if (le >= 1 && le <= a.L) out[le] = w[p].re * inv;
-                if (lod >= 1 && lod <= a.L) out[lod] = w[p].im * inv;
+                if (le >= 1 && le <= a.L) {
+                    double sv = w[p].re * inv;
+                    if (unit) sv += ((double)(F - le) + ((double)Pl[F - le] + (PF - (double)Pl[le]))) * (1.0 / 3.0);
+                    out[le] = sv;
+                }
+                if (lod >= 1 && lod <= a.L) {
+                    double sv = w[p].im * inv;
+                    if (unit) sv += ((double)(F - lod) + ((double)Pl[F - lod] + (PF - (double)Pl[lod]))) * (1.0 / 3.0);
+                    out[lod] = sv;
+                }
             }
         }
     }
+#undef SR_RFFT_LOAD
+#undef SR_RFFT_LOAD1
+}
+
+// TR needs the whole series in the prologue's registers (3 planes x NZ pairs): the HALF variants
+template <int N1, bool HALF>
+constexpr bool rfft_use_tr() { return HALF; }
+template <int N1, bool HALF>
+constexpr size_t rfft_lds_bytes()
+{
+    constexpr int NZ = HALF ? (N1 == 12 ? 8 : N1 / 2) : N1;
+    // transform image + the 16 x 16 step-2 twiddles (+ TR: prefix sums P[0 .. 512 NZ] as float32, 8 pad, 8 doubles of block
+    // totals, 8 floats of wave maxima)
+    return (size_t)(rfft_lds_slots(N1) + 256) * sizeof(cplx) + (rfft_use_tr<N1, HALF>() ? (size_t)(512 * NZ + 8 + 16 + 8) * sizeof(float) : 0);
 }
 
 template <int N1, bool HALF>
 int launch_ct_rfft_h(sr_ctx *ctx, const CtRfftArgs &a, int64_t series)
 {
-    const size_t lds = (size_t)(rfft_lds_slots(N1) + 256) * sizeof(cplx);      // transform image + the 16 x 16 step-2 twiddles
+    constexpr bool TR = rfft_use_tr<N1, HALF>();
+    const size_t lds = rfft_lds_bytes<N1, HALF>();
     if (lds > 64 * 1024)
-        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ct_rfft<N1, HALF>),
+        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ct_rfft<N1, HALF, TR>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_ct_rfft<N1, HALF>), dim3((unsigned)series), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_ct_rfft<N1, HALF, TR>), dim3((unsigned)series), dim3(256), lds, ctx->stream, a);
     SR_HIP(hipGetLastError());
     return 0;
 }
-template <int N1>
+// With L = F/2 the two transform lengths are tied to the chunk length: M = 6144 serves 4096 < 1.5 F <= 6144, i.e. F <= 4096
+// (at most 8 of the 12 input blocks are non-zero: HALF), M = 8192 serves 4096 < F <= 5461 (more than half: not HALF).
+// Only those two instantiations exist.
 int launch_ct_rfft(sr_ctx *ctx, const CtRfftArgs &a, int64_t series)
 {
-    constexpr int NZ = N1 == 12 ? 8 : N1 / 2;
-    return a.F <= 512 * NZ ? launch_ct_rfft_h<N1, true>(ctx, a, series) : launch_ct_rfft_h<N1, false>(ctx, a, series);
+    if (a.F + a.L <= 6144) {
+        SR_REQUIRE(a.F <= 4096, -3, "k_ct_rfft<12>: F=%d does not fit 8 input blocks", a.F);
+        return launch_ct_rfft_h<12, true>(ctx, a, series);
+    }
+    SR_REQUIRE(a.F + a.L <= 8192, -3, "k_ct_rfft<16>: F=%d too long", a.F);
+    return launch_ct_rfft_h<16, false>(ctx, a, series);
 }
 
-// mean / std over the R replicate chunks, calculate-Ct-from-traj.py:226-228
+// mean / std over the R replicate chunks, calculate-Ct-from-traj.py:226-228.  One workgroup owns a tile of kFinV vectors x
+// kFinD lags: the raw sums are read along the lags (a wave = 64 consecutive lags of one vector), the results leave in BOTH
+// orientations -- (lags, vectors) as the reference holds them, through an LDS tile so that 16 consecutive vectors of a lag
+// go out together, and (vectors, lags) for the fit, straight from the registers.  (The thread-per-element version wrote
+// the (lags, vectors) arrays with a stride of nV doubles: 445 MB of HBM traffic for 218 MB of data, and two transposition
+// launches behind it.)
+constexpr int kFinV = 16, kFinD = 64;
 __global__ __launch_bounds__(256) void k_ct_finalize(const double *__restrict__ psum, int R, int F, int L, int Lp,
-                                                     int64_t nV, double *__restrict__ Ct, double *__restrict__ dCt)
+                                                     int64_t nV, double *__restrict__ Ct, double *__restrict__ dCt,
+                                                     double *__restrict__ CtT, double *__restrict__ dCtT)
 {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nV * L) return;
-    const int64_t v = idx / L;
-    const int d = (int)(idx - v * L) + 1;
-    const double *p = psum + v * R * Lp + d;
-    const double n = (double)(F - d);
-    double m = 0.0;
-    for (int r = 0; r < R; ++r) m += 1.5 * (p[(int64_t)r * Lp] / n) - 0.5;
-    m /= (double)R;
-    double s = 0.0;
-    for (int r = 0; r < R; ++r) {
-        const double e = (1.5 * (p[(int64_t)r * Lp] / n) - 0.5) - m;
-        s += e * e;
+    __shared__ double tm[kFinV][kFinD + 1], ts[kFinV][kFinD + 1];
+    const int tid = threadIdx.x;
+    const int d0 = blockIdx.x * kFinD;                  // lag index - 1 of the tile's first column
+    const int64_t v0 = (int64_t)blockIdx.y * kFinV;
+    const double rootR = sqrt((double)R) - 1.0;
+    {
+        const int dl = tid & 63;
+        const int d = d0 + dl + 1;
+#pragma unroll
+        for (int i = 0; i < kFinV / 4; ++i) {
+            const int vl = (tid >> 6) + 4 * i;
+            const int64_t v = v0 + vl;
+            if (d > L || v >= nV) continue;
+            const double *p = psum + v * R * Lp + d;
+            const double n = (double)(F - d);
+            double m = 0.0;
+            for (int r = 0; r < R; ++r) m += 1.5 * (p[(int64_t)r * Lp] / n) - 0.5;
+            m /= (double)R;
+            double s = 0.0;
+            for (int r = 0; r < R; ++r) {
+                const double e = (1.5 * (p[(int64_t)r * Lp] / n) - 0.5) - m;
+                s += e * e;
+            }
+            const double sd = sqrt(s / (double)R) / rootR;
+            tm[vl][dl] = m;
+            ts[vl][dl] = sd;
+            if (CtT) {
+                CtT[v * L + (d - 1)] = m;
+                dCtT[v * L + (d - 1)] = sd;
+            }
+        }
     }
-    const int64_t o = (int64_t)(d - 1) * nV + v;
-    Ct[o] = m;
-    dCt[o] = sqrt(s / (double)R) / (sqrt((double)R) - 1.0);
+    __syncthreads();
+    {
+        const int vl = tid & 15;
+        const int64_t v = v0 + vl;
+#pragma unroll
+        for (int i = 0; i < kFinD / 16; ++i) {
+            const int dl = (tid >> 4) + 16 * i;
+            const int d = d0 + dl + 1;
+            if (d > L || v >= nV) continue;
+            const int64_t o = (int64_t)(d - 1) * nV + v;
+            Ct[o] = tm[vl][dl];
+            dCt[o] = ts[vl][dl];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_transpose_f64(const double *__restrict__ in, int64_t rows, int64_t cols,
@@ -1261,16 +1454,12 @@ int sr_ct_palmer_sums_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64
             ctx->fft_table_ready = 1;
         }
         if (ctx->ct_fft == 2 && need > 4096) {
-            // real-input formulation: half-length transforms, three workgroups per CU
+            // real-input formulation: half-length transforms, two workgroups per CU
             CtRfftArgs ra;
             ra.soa = soa; ra.Npad = Npad; ra.chunk_start = cs_dev; ra.psum = psum;
             ra.R = (int)R; ra.F = (int)F; ra.L = (int)L; ra.Lp = (int)Lp;
-            if (need <= 6144) {
-                ra.tab = tab + 2 * 1280;
-                return launch_ct_rfft<12>(ctx, ra, series);
-            }
-            ra.tab = tab + 2 * (1280 + 768);
-            return launch_ct_rfft<16>(ctx, ra, series);
+            ra.tab = need <= 6144 ? tab + 2 * 1280 : tab + 2 * (1280 + 768);
+            return launch_ct_rfft(ctx, ra, series);
         }
         CtFftArgs fa;
         fa.soa = soa; fa.Npad = Npad; fa.chunk_start = cs_dev; fa.tab = tab; fa.psum = psum;
@@ -1291,18 +1480,26 @@ int sr_ct_palmer_sums_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64
     return rc;
 }
 
-int sr_ct_finalize_f64_dev(sr_ctx *ctx, const double *psum, int64_t R, int64_t F, int64_t nV, double *Ct, double *dCt)
+int sr_ct_finalize_t_f64_dev(sr_ctx *ctx, const double *psum, int64_t R, int64_t F, int64_t nV, double *Ct, double *dCt,
+                             double *CtT, double *dCtT)
 {
     SR_CHECK_CTX(ctx);
     SR_REQUIRE(psum && Ct && dCt, -2, "sr_ct_finalize_f64_dev: null pointer");
+    SR_REQUIRE((CtT == nullptr) == (dCtT == nullptr), -2, "sr_ct_finalize_t_f64_dev: CtT and dCtT go together");
     SR_REQUIRE(R >= 1 && F >= 2 && nV >= 1, -3, "sr_ct_finalize_f64_dev: bad shape");
     const int64_t L = F / 2;
     const int64_t Lp = sr_ct_psum_stride(F);
-    const int64_t tot = nV * L;
-    hipLaunchKernelGGL(k_ct_finalize, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, psum, (int)R,
-                       (int)F, (int)L, (int)Lp, nV, Ct, dCt);
+    const int64_t gx = (L + kFinD - 1) / kFinD, gy = (nV + kFinV - 1) / kFinV;
+    SR_REQUIRE(gy <= 65535, -3, "sr_ct_finalize_f64_dev: too many vectors in one call (%lld)", (long long)nV);
+    hipLaunchKernelGGL(k_ct_finalize, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ctx->stream, psum, (int)R, (int)F, (int)L,
+                       (int)Lp, nV, Ct, dCt, CtT, dCtT);
     SR_HIP(hipGetLastError());
     return 0;
+}
+
+int sr_ct_finalize_f64_dev(sr_ctx *ctx, const double *psum, int64_t R, int64_t F, int64_t nV, double *Ct, double *dCt)
+{
+    return sr_ct_finalize_t_f64_dev(ctx, psum, R, F, nV, Ct, dCt, nullptr, nullptr);
 }
 
 int sr_ct_palmer_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t R, int64_t F, int64_t nV,

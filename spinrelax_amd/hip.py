@@ -155,8 +155,13 @@ class Context:
         check(self.lib.sr_ct_palmer_sums_f32_dev(self.h, soa_ptr, Npad, R, F, nV, None if cs is None else _ptr(cs), mode, psum_ptr),
               'sr_ct_palmer_sums_f32_dev')
 
-    def ct_finalize_dev(self, psum_ptr, R, F, nV, Ct_ptr, dCt_ptr):
-        check(self.lib.sr_ct_finalize_f64_dev(self.h, psum_ptr, R, F, nV, Ct_ptr, dCt_ptr), 'sr_ct_finalize_f64_dev')
+    def ct_finalize_dev(self, psum_ptr, R, F, nV, Ct_ptr, dCt_ptr, CtT_ptr=None, dCtT_ptr=None):
+        """mean / std over the chunks; with CtT_ptr / dCtT_ptr the same launch also writes the (nV, L) copies the fits read"""
+        if CtT_ptr is None:
+            check(self.lib.sr_ct_finalize_f64_dev(self.h, psum_ptr, R, F, nV, Ct_ptr, dCt_ptr), 'sr_ct_finalize_f64_dev')
+        else:
+            check(self.lib.sr_ct_finalize_t_f64_dev(self.h, psum_ptr, R, F, nV, Ct_ptr, dCt_ptr, CtT_ptr, dCtT_ptr),
+                  'sr_ct_finalize_t_f64_dev')
 
     def psum_stride(self, F):
         return int(self.lib.sr_ct_psum_stride(F))

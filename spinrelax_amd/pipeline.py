@@ -310,8 +310,11 @@ class DevicePipeline:
             self.stage_ct_finalize(s)
 
     def stage_ct_finalize(self, s=None):
+        """mean / std over the chunks, written in both orientations by one launch: (L, V) as the reference holds C(t) and
+        (V, L) for the fits (stage_transpose is only needed behind a finalize that did not write them)"""
         s = s or self.slots[0]
-        self.ctx.ct_finalize_dev(s.psum.data_ptr(), self.R, self.F, self.V, s.Ct.data_ptr(), s.dCt.data_ptr())
+        self.ctx.ct_finalize_dev(s.psum.data_ptr(), self.R, self.F, self.V, s.Ct.data_ptr(), s.dCt.data_ptr(),
+                                 s.CtT.data_ptr(), s.dCtT.data_ptr())
 
     def stage_hist(self, s=None, soa=None):
         s = s or self.slots[0]
@@ -374,7 +377,6 @@ class DevicePipeline:
                 self.stage_hist(s)
                 if events is not None:
                     events[3].record(self.main)
-                self.stage_transpose(s)
                 s.front_done = torch.cuda.Event()
                 s.front_done.record(self.main)
                 s.hist_done = s.front_done
@@ -413,8 +415,6 @@ class DevicePipeline:
                     events[3].record(main)
             self._ct_done_ev[b] = torch.cuda.Event()            # "the C(t) kernel is done with this plane buffer"
             self._ct_done_ev[b].record(main)
-            if not self.tail_on_slot_stream:
-                self.stage_transpose(s)
             s.front_done = torch.cuda.Event()
             s.front_done.record(main)
             s.hist_done = s.front_done
@@ -462,7 +462,6 @@ class DevicePipeline:
                 self.stage_ct_finalize(s)
                 s.psum_free = torch.cuda.Event()
                 s.psum_free.record(s.stream)
-                self.stage_transpose(s)
             if events is not None and len(events) > 5:
                 events[4].record(s.stream)
             self.stage_fit(s)

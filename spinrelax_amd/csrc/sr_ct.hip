@@ -918,10 +918,16 @@ __device__ __forceinline__ void rfft_workgroup(cplx *v, cplx *w, cplx *lds, cplx
 // (an orthonormal change of basis on the diagonal (x^2, y^2, z^2); exact for ANY vectors).  The bond vectors are unit
 // vectors rounded to float32: s = 1 + e with |e| < 3e-7, so the trace term needs no transform,
 //     sum_{j < F-d} s_j s_{j+d} = (F - d) + P[F-d] + (P[F] - P[d]) + O(F e^2),      P[k] = sum_{j<k} e_j  (prefix sums),
-// and the neglected O(e^2) part is < 1e-13 of C(t).  The prologue computes e for every frame of the series (it holds x, y, z
-// for the first signal anyway), the workgroup scans it once, and P stays in LDS as float32 (16 KB) until the lags are
-// written.  A series with any |e| >= kUnitTol (not a unit vector: zero vectors from the 0/0 guard of vecnorm_NDarray,
-// callers with unnormalised input) runs the sixth transform on s instead -- decided per workgroup, same kernel.
+// and the neglected O(e^2) part is < 1e-13 of C(t).  P[F-d] + (P[F] - P[d]) = G[0] + G[d] with G[d] = sum_{j=d}^{F-d-1} e_j, the
+// sum over a window that shrinks from both ends: a suffix scan over HALF the series.  The prologue (which holds x, y, z for the
+// first signal anyway) forms e, the workgroup scans it once in float32 with DPP adds, and the finished term
+// ((F - d) + G[0] + G[d]) / 3 stays in LDS as float64 (16 KB) until the lags are written: one look-up and one fma per lag.
+// Measured (rocprofv3 PMC, cfg3): 7.1 % fewer VALU instructions per launch than the six-signal kernel (a seventh of the
+// transforms minus this bookkeeping), 3.4 % fewer wave cycles, 0.95 -> 0.915 ms: the kernel's waves spend 36 % of their life
+// at barriers / waitcnt and 22 % in issue stalls, which a shorter instruction stream does not shorten.  (The first version --
+// float64 prefix sums over the whole series through ds_bpermute shuffles, three look-ups per lag -- cost as much as it saved.)
+// A series with any |e| >= kUnitTol (not a unit vector: zero vectors from the 0/0 guard of vecnorm_NDarray, callers with
+// unnormalised input) runs the sixth transform on s instead -- decided per workgroup, same kernel.
 constexpr double kUnitTol = 5e-7;
 
 template <bool TR> __device__ __forceinline__ int rfft_plane_a(int c) { return TR ? (c == 4 ? 1 : 0) : (c < 3 ? c : (c == 5 ? 1 : 0)); }
@@ -940,7 +946,7 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
     cplx *lds = reinterpret_cast<cplx *>(fft_smem);
     constexpr int H = N1 * 256, M = 2 * H;
     constexpr int NZ = HALF ? (N1 == 12 ? 8 : N1 / 2) : N1;
-    float *Pl = reinterpret_cast<float *>(lds + rfft_lds_slots(N1) + 256);     // TR: prefix sums P[0 .. 512 NZ], then 8 floats
+    float *Pl = reinterpret_cast<float *>(lds + rfft_lds_slots(N1) + 512);     // TR: the trace term's table (2049 doubles), then scan scratch
     const int tid0 = threadIdx.x;
     const int v = blockIdx.x / a.R, r = blockIdx.x - v * a.R;
     const int F = a.F;
@@ -973,8 +979,10 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
     float2 ar[NZ], br[NZ];
 #define SR_RFFT_LOAD1(DST, PLANE, T)                                                             \
     {                                                                                            \
+        /* the plane index is workgroup-uniform: say so, or the descriptor is built in VGPRs and every load becomes a */ \
+        /* waterfall loop (readfirstlane + compare + masked load), 13 instructions and a serialisation each          */ \
         const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                    \
-            const_cast<float *>(px + (int64_t)(PLANE) * a.Npad), (short)0, F * 4, 0x00020000);   \
+            const_cast<float *>(px + (int64_t)__builtin_amdgcn_readfirstlane(PLANE) * a.Npad), (short)0, F * 4, 0x00020000); \
         if (even) {                                                                              \
             _Pragma("unroll") for (int n1 = 0; n1 < NZ; ++n1)                                    \
                 DST[n1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_, 8 * ((T) + 256 * n1), 0, 0)); \
@@ -999,17 +1007,29 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
         lds[rfft_lds_slots(N1) + tid0] = cplx{a.tab[2 * (256 + j)], a.tab[2 * (256 + j) + 1]};
     }
 
+    // step-1 twiddle base w_H^tid: the same for every transform of the series.  From a table in LDS, not from global
+    // memory: vmcnt counts in order, so waiting for a global load issued behind the sample prefetch drains the prefetch too
+    // (measured: 0.94 -> 1.00 ms although a seventh of the transforms was gone), and carrying it in registers across the
+    // transforms costs four of the VGPRs the loop does not have.  Ordered before its first read by the first barrier below.
+    lds[rfft_lds_slots(N1) + 256 + tid0] = cplx{a.tab[2 * tid0], a.tab[2 * tid0 + 1]};
     cplx sig[N1];                 // input of the next transform (entries >= NZ stay zero)
 #pragma unroll
     for (int n1 = 0; n1 < N1; ++n1) sig[n1] = cplx{0.0, 0.0};
     int nsig = 6;
     if (TR) {
-        // ---- prologue of the traceless form: signal 0 = 2 z^2 - x^2 - y^2, e = |u|^2 - 1 and its prefix sums ----
-        double e1[NZ], e2[NZ], emax = 0.0;
+        // ---- prologue of the traceless form: signal 0 = 2 z^2 - x^2 - y^2, and the trace term's table ----
+        // e_j = |u_j|^2 - 1 (float64, then rounded to float32: |e| < 3e-7, so 1e-14 absolute).  What the lags need is
+        //     P[F-d] + (P[F] - P[d]) = G[0] + G[d],      G[d] = sum_{j = d}^{F-d-1} e_j  (the window that shrinks from both ends),
+        // and G is a suffix sum of h_i = e_i + e_{F-1-i} (i < F-1-i; the centre frame once): a scan over HALF the series,
+        // in float32 (sums of < 4096 terms of 1e-7: rounding 1e-12 absolute against F - d > 2000), with DPP adds.
+        float emax = 0.f;
+        float *E = reinterpret_cast<float *>(lds);          // scratch in the still unused transform image
+        float *aux = Pl + 2 * 2056;                         // behind the table: [0 .. 4) wave totals, [4 .. 8) wave maxima of |e|
         {
             float2 zr[NZ];
             SR_RFFT_LOAD(0, tid0)                      // x, y
             SR_RFFT_LOAD1(zr, 2, tid0)
+            const bool full = F == 512 * NZ;           // no frame of the loaded blocks lies behind the chunk
 #pragma unroll
             for (int n1 = 0; n1 < NZ; ++n1) {
                 const double x0 = (double)ar[n1].x, x1 = (double)ar[n1].y, y0 = (double)br[n1].x, y1 = (double)br[n1].y;
@@ -1017,58 +1037,68 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
                 const double q0 = fma(x0, x0, y0 * y0), q1 = fma(x1, x1, y1 * y1), zz0 = z0 * z0, zz1 = z1 * z1;
                 sig[n1] = cplx{(zz0 + zz0) - q0, (zz1 + zz1) - q1};
                 const int f0 = 2 * (tid0 + 256 * n1);
-                const double ea = f0 < F ? (q0 + zz0) - 1.0 : 0.0, eb = f0 + 1 < F ? (q1 + zz1) - 1.0 : 0.0;
-                e1[n1] = eb;
-                e2[n1] = ea + eb;
-                emax = fmax(emax, fmax(fabs(ea), fabs(eb)));
+                float ea = (float)((q0 + zz0) - 1.0), eb = (float)((q1 + zz1) - 1.0);
+                if (!full) {
+                    ea = f0 < F ? ea : 0.f;
+                    eb = f0 + 1 < F ? eb : 0.f;
+                }
+                *reinterpret_cast<float2 *>(E + f0) = make_float2(ea, eb);
+                emax = fmaxf(emax, fmaxf(fabsf(ea), fabsf(eb)));
             }
         }
         SR_RFFT_LOAD(1, tid0)
-        // scan scratch in the (still unused) transform image: S[n1][t] pair sums, then block totals and wave maxima behind P
-        double *S = reinterpret_cast<double *>(lds);
-        float *aux = Pl + 512 * NZ + 8;                 // 8 doubles: block totals; then floats [16 .. 20): wave maxima of |e|
-#pragma unroll
-        for (int n1 = 0; n1 < NZ; ++n1) S[n1 * 256 + tid0] = e2[n1];
+        const int lane = tid0 & 63, wave = tid0 >> 6;
         {
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) emax = fmax(emax, __shfl_xor(emax, m, 64));
-            if ((tid0 & 63) == 0) aux[16 + (tid0 >> 6)] = (float)emax;     // float32: only compared with the tolerance
+            // wave maximum with DPP moves (an inclusive max-scan: lane 63 ends up with the maximum; |e| >= 0, so 0 is neutral)
+#define SR_DPP_MAX(CTRL, RM) emax = fmaxf(emax, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, emax), CTRL, RM, 0xF, false)));
+            SR_DPP_MAX(0x111, 0xF) SR_DPP_MAX(0x112, 0xF) SR_DPP_MAX(0x114, 0xF) SR_DPP_MAX(0x118, 0xF) SR_DPP_MAX(0x142, 0xA) SR_DPP_MAX(0x143, 0xC)
+#undef SR_DPP_MAX
+            if (lane == 63) aux[4 + wave] = emax;
         }
         __syncthreads();
+        // thread t owns i = 8 b .. 8 b + 7 with b = 255 - t: an inclusive PREFIX scan over t is the suffix sum over i
+        const int i0 = 8 * (255 - tid0);
+        float sfx[8], incl;
         {
-            // wave w scans the blocks n1 = w, w + 4, ...: lane l owns the pair sums 4 l .. 4 l + 3 of the block
-            const int lane = tid0 & 63, wave = tid0 >> 6;
-            for (int n1 = wave; n1 < NZ; n1 += 4) {
-                double *Sb = S + n1 * 256 + 4 * lane;
-                const double a0 = Sb[0], a1 = a0 + Sb[1], a2 = a1 + Sb[2], a3 = a2 + Sb[3];
-                double inc = a3;
+            const float4 ea = *reinterpret_cast<const float4 *>(E + i0), eb = *reinterpret_cast<const float4 *>(E + i0 + 4);
+            const float ei[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+            float h[8];
 #pragma unroll
-                for (int m = 1; m < 64; m <<= 1) {
-                    const double o = __shfl_up(inc, m, 64);
-                    if (lane >= m) inc += o;
-                }
-                const double exc = inc - a3;
-                Sb[0] = exc + a0; Sb[1] = exc + a1; Sb[2] = exc + a2; Sb[3] = exc + a3;
-                if (lane == 63) reinterpret_cast<double *>(aux)[n1] = inc;      // block total
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k, j = F - 1 - i;               // j > 0: F > 2730 for this transform length
+                const float ej = E[j];
+                h[k] = i < j ? ei[k] + ej : (i == j ? ei[k] : 0.f);
             }
+            sfx[7] = h[7];
+#pragma unroll
+            for (int k = 6; k >= 0; --k) sfx[k] = h[k] + sfx[k + 1];
+            // wave-wide inclusive scan of the thread totals: row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then row_bcast15 /
+            // row_bcast31 (the AMDGPU atomic optimiser's sequence); lanes without a source add 0
+            float vsc = sfx[0];
+            vsc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, vsc), 0x111, 0xF, 0xF, false));
+            vsc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, vsc), 0x112, 0xF, 0xF, false));
+            vsc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, vsc), 0x114, 0xF, 0xF, false));
+            vsc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, vsc), 0x118, 0xF, 0xF, false));
+            vsc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, vsc), 0x142, 0xA, 0xF, false));
+            vsc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, vsc), 0x143, 0xC, 0xF, false));
+            incl = vsc;
+            if (lane == 63) aux[wave] = incl;
         }
-        __syncthreads();
+        __syncthreads();                                     // every read of E is done: the first transform may use the image
         {
-            const double *tot = reinterpret_cast<const double *>(aux);
-            double off = 0.0;
+            float off = incl - sfx[0];
 #pragma unroll
-            for (int n1 = 0; n1 < NZ; ++n1) {
-                const double inc = S[n1 * 256 + tid0] + off;             // prefix through frame 2 m + 1, m = tid0 + 256 n1
-                const int m = tid0 + 256 * n1;
-                Pl[2 * m + 1] = (float)(inc - e1[n1]);
-                Pl[2 * m + 2] = (float)inc;
-                off += tot[n1];
-            }
-            if (tid0 == 0) Pl[0] = 0.f;
-            const float mx = fmaxf(fmaxf(aux[16], aux[17]), fmaxf(aux[18], aux[19]));
+            for (int w2 = 0; w2 < 3; ++w2) off += w2 < wave ? aux[w2] : 0.f;
+            const float G0 = (aux[0] + aux[1]) + (aux[2] + aux[3]);          // sum of every e of the series
+            // Tt[d] = ((F - d) + G[0] + G[d]) / 3: the finished trace term of lag d, float64 -- one fma per lag at the end
+            double *Tt = reinterpret_cast<double *>(Pl);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                Tt[i0 + k] = ((double)(F - (i0 + k)) + (double)(G0 + (sfx[k] + off))) * (1.0 / 3.0);
+            if (tid0 == 0) Tt[2048] = ((double)(F - 2048) + (double)G0) * (1.0 / 3.0);
+            const float mx = fmaxf(fmaxf(aux[4], aux[5]), fmaxf(aux[6], aux[7]));
             nsig = __builtin_amdgcn_readfirstlane(mx < (float)kUnitTol ? 5 : 6);
         }
-        __syncthreads();                                // S is read: the first transform may overwrite the image
     } else {
         SR_RFFT_LOAD(0, tid0)
 #pragma unroll
@@ -1084,8 +1114,7 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
         const bool act = k1 < N1;
         const int pt = k1 != 0 ? (N1 - k1) * 16 + (15 - k2a) : (k2a != 0 ? 16 - k2a : 0);
         const int off0 = tid == 0 ? 1 : 0;
-        // step-1 twiddle base w_H^tid
-        const cplx base1 = opaque(cplx{a.tab[2 * tid], a.tab[2 * tid + 1]});
+        const cplx base1 = opaque(lds[rfft_lds_slots(N1) + 256 + tid]);
         cplx w[16];
         rfft_workgroup<N1>(sig, w, lds, base1, tid);
         // own row again, now in frequency order k2b; then every thread reads the partner frequencies of its 8 pairs
@@ -1129,21 +1158,23 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
         // assignment would keep the transform's in-place leftovers in `sig` alive through the spectrum step.
         {
             const int cn = c + 1;
-            const bool dsq = TR && cn == 1;                        // x^2 - y^2 = (x - y)(x + y)
             // keep these products HERE: nothing ties them to this point but their inputs, and scheduled above the spectrum
             // step (where w[16] is live) they push the accumulators into scratch
 #pragma unroll
             for (int n1 = 0; n1 < NZ; ++n1)
                 asm volatile("" : "+v"(ar[n1].x), "+v"(ar[n1].y), "+v"(br[n1].x), "+v"(br[n1].y));
 #pragma unroll
-            for (int n1 = 0; n1 < N1; ++n1) {
-                if (n1 >= NZ) {
-                    sig[n1] = cplx{0.0, 0.0};
-                    continue;
+            for (int n1 = NZ; n1 < N1; ++n1) sig[n1] = cplx{0.0, 0.0};
+            if (TR && cn == 1) {                                   // x^2 - y^2
+#pragma unroll
+                for (int n1 = 0; n1 < NZ; ++n1) {
+                    const double a0 = (double)ar[n1].x, a1 = (double)ar[n1].y, b0 = (double)br[n1].x, b1 = (double)br[n1].y;
+                    sig[n1] = cplx{fma(a0, a0, -(b0 * b0)), fma(a1, a1, -(b1 * b1))};
                 }
-                const double a0 = (double)ar[n1].x, a1 = (double)ar[n1].y, b0 = (double)br[n1].x, b1 = (double)br[n1].y;
-                const double A0 = dsq ? a0 - b0 : a0, A1 = dsq ? a1 - b1 : a1, B0 = dsq ? a0 + b0 : b0, B1 = dsq ? a1 + b1 : b1;
-                sig[n1] = cplx{A0 * B0, A1 * B1};
+            } else {
+#pragma unroll
+                for (int n1 = 0; n1 < NZ; ++n1)
+                    sig[n1] = cplx{(double)ar[n1].x * (double)br[n1].x, (double)ar[n1].y * (double)br[n1].y};
             }
             if (TR && cn == 5 && nsig == 6) {          // not a unit vector: s = x^2 + y^2 + z^2 itself (rare; the z load is exposed)
 #pragma unroll
@@ -1195,26 +1226,18 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
         }
         __syncthreads();
         cplx w[16];
-        rfft_workgroup<N1>(yin, w, lds, opaque(cplx{a.tab[2 * tid], a.tab[2 * tid + 1]}), tid);
+        rfft_workgroup<N1>(yin, w, lds, opaque(lds[rfft_lds_slots(N1) + 256 + tid]), tid);
         if (act) {
             double *out = a.psum + ((int64_t)v * a.R + r) * a.Lp;
             const double inv = 1.0 / (double)M;
             const bool unit = TR && nsig == 5;
-            const double PF = unit ? (double)Pl[F] : 0.0;
+            const double *Tt = reinterpret_cast<const double *>(Pl);
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
                 const int m = k1 + N1 * (k2a + 16 * bitrev<4>(p));
                 const int le = 2 * m, lod = 2 * m - 1;
-                if (le >= 1 && le <= a.L) {
-                    double sv = w[p].re * inv;
-                    if (unit) sv += ((double)(F - le) + ((double)Pl[F - le] + (PF - (double)Pl[le]))) * (1.0 / 3.0);
-                    out[le] = sv;
-                }
-                if (lod >= 1 && lod <= a.L) {
-                    double sv = w[p].im * inv;
-                    if (unit) sv += ((double)(F - lod) + ((double)Pl[F - lod] + (PF - (double)Pl[lod]))) * (1.0 / 3.0);
-                    out[lod] = sv;
-                }
+                if (le >= 1 && le <= a.L) out[le] = unit ? fma(w[p].re, inv, Tt[le]) : w[p].re * inv;
+                if (lod >= 1 && lod <= a.L) out[lod] = unit ? fma(w[p].im, inv, Tt[lod]) : w[p].im * inv;
             }
         }
     }
@@ -1229,9 +1252,9 @@ template <int N1, bool HALF>
 constexpr size_t rfft_lds_bytes()
 {
     constexpr int NZ = HALF ? (N1 == 12 ? 8 : N1 / 2) : N1;
-    // transform image + the 16 x 16 step-2 twiddles (+ TR: prefix sums P[0 .. 512 NZ] as float32, 8 pad, 8 doubles of block
-    // totals, 8 floats of wave maxima)
-    return (size_t)(rfft_lds_slots(N1) + 256) * sizeof(cplx) + (rfft_use_tr<N1, HALF>() ? (size_t)(512 * NZ + 8 + 16 + 8) * sizeof(float) : 0);
+    // transform image + the 16 x 16 step-2 twiddles + the 256 step-1 twiddle bases (+ TR: the trace term's table Tt[0 .. 2048]
+    // as float64, then 4 wave totals and 4 wave maxima)
+    return (size_t)(rfft_lds_slots(N1) + 512) * sizeof(cplx) + (rfft_use_tr<N1, HALF>() ? (size_t)(2 * 2056 + 16) * sizeof(float) : 0);
 }
 
 template <int N1, bool HALF>

@@ -145,6 +145,20 @@ int sr_rotate_hist_f32_dev(sr_ctx *, const float *soa, int64_t Npad, int64_t N, 
 int sr_rotate_hist_f32(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
                        const double *q, const double *edges_phi, int nphi, const double *edges_cos, int ncos,
                        double *hist, double *vecsum, double *outer, int64_t block_len);
+/* Kernel 0 and kernel 2 in ONE pass over the frame-major vectors: writes the planes sr_pack_soa_f32_dev writes (all Ntot
+ * frames, zero-padded to Npad) and, from the same registers, what sr_rotate_hist_f32_dev computes -- histogram, vector sums
+ * and per-block outer-product sums -- over
+ *   chunk_start_host == NULL: the first N_hist frames, S2 blocks of block_len frames (0 = one block), or
+ *   chunk_start_host != NULL: the R chunks [chunk_start[r], chunk_start[r] + block_len) of kernel 1 (ascending, not
+ *                             overlapping: reformat_vecs_by_tau's used frames, calculate-Ct-from-traj.py:245-275); one S2
+ *                             block per chunk, N_hist ignored.
+ * Same arguments and results as the two calls it replaces (counts identical; the float64 sums are added in another order:
+ * 1e-13).  Returns -6 when the histogram is too large for this kernel's LDS layout (more than ~2 600 bins): call the two
+ * kernels then.  Uses context work areas: one stream at a time, like sr_rotate_hist_f32_dev. */
+int sr_pack_hist_f32_dev(sr_ctx *, const float *vecs, int64_t Ntot, int64_t Vtot, int64_t v0, int64_t nV, float *soa,
+                         int64_t Npad, int64_t N_hist, const int64_t *chunk_start_host, int64_t R, int64_t block_len,
+                         const double *q_host, const double *edges_phi_host, int nphi, const double *edges_cos_host, int ncos,
+                         double *hist, double *vecsum, double *outer);
 /* rotated vectors themselves, float64 (N, nV, 3) like the reference returns (for --vecDist output). */
 int sr_rotate_vectors_f32(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
                           const double *q, double *out);

@@ -1,5 +1,6 @@
 // sr_core.hip -- context, device memory, stream and HIP-event timing of libspinrelax_hip.so
 #include "sr_internal.h"
+#include <cstdlib>
 #include <cstring>
 
 static thread_local char g_err[1024] = "";
@@ -90,6 +91,7 @@ void sr_destroy(sr_ctx *ctx)
         if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    free(ctx->tab_shadow);
     delete ctx;
 }
 

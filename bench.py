@@ -102,7 +102,6 @@ def parse():
     ap.add_argument('--ct-fft', type=int, default=-1, help='kernel 1: 2 = real-input FFT (k_ct_rfft) where it applies, 1 = complex FFT (k_ct_fft), 0 = direct (k_ct_palmer); -1 = library default (2)')
     ap.add_argument('--depth', type=int, default=5, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--fuse-pack-hist', type=int, default=0, help='1: the fused pack + histogram kernel (one pass over the input; measured slower than the two kernels, see DESIGN.md)')
     ap.add_argument('--no-kernel-profile', action='store_true', help='skip the per-kernel alone / saturated timings after the timed region (the `kernels` entries then only carry in-pipeline durations)')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
     ap.add_argument('--all-ranks-on-device0', action='store_true', help='rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)')
@@ -265,7 +264,7 @@ def main():
     pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], depth=args.depth,
                           stream=torch.cuda.Stream(device=dev, priority=args.main_priority), reserve_cus=args.reserve_cus, aux_cus=args.aux_cus,
                           fit_priority=args.fit_priority, plane_buffers=args.plane_buffers,
-                          fits_on_reserved_only=bool(args.fits_on_reserved_only), hist_on_aux=not args.hist_on_main, fuse_pack_hist=bool(args.fuse_pack_hist), **pkw)
+                          fits_on_reserved_only=bool(args.fits_on_reserved_only), hist_on_aux=not args.hist_on_main, **pkw)
     stream = pipe.main
     if args.dev_skip_fits:
         pipe.stage_fit = lambda s=None: None
@@ -356,7 +355,7 @@ def main():
         def _pairs(i, j):
             out = []
             for e in events:
-                try:                     # the fused pack + histogram launch runs one batch ahead: the last step records none
+                try:
                     out.append(e[i].elapsed_time(e[j]))
                 except (ValueError, RuntimeError):
                     pass
@@ -369,7 +368,6 @@ def main():
     nfits_by_order = {str(k): int(np.size(v)) for k, v in pipe.nfev_last.items()}
     nfev_step = nfev_timed / max(1, args.steps * max(1, args.repeats))
     depth_used, reserve_used = pipe.depth, pipe.reserve_cus
-    fused_used = bool(pipe.fused)
     listDoG = pipe.listDoG
     del events, gbuf
     pipe.close()
@@ -403,8 +401,6 @@ def main():
             return float(min(out))
 
         alone['pack'] = timed(lambda: p1.stage_pack(vecs))
-        if q is not None and p1.fused:
-            alone['pack_hist'] = timed(lambda: p1.stage_pack_hist(vecs, (s0.hist, s0.vecsum, s0.outer)))
         alone['ct'] = timed(lambda: p1.stage_ct(s0, finalize=False))
         alone['ct_finalize'] = timed(lambda: p1.stage_ct_finalize(s0))
         if q is not None:
@@ -507,17 +503,11 @@ def main():
             entry('k_ct_palmer', 'valu-fp32 (non-MFMA vector FMA; FP32 MFMA peak is the same)', 8.0 * triples, 1e12, PEAK_FP32_TFLOPS, 'TFLOP/s',
                   ct_ms, alone.get('ct'), formulation='direct shifted products, 8 flop per triple', algorithmic_bytes=12 * N * V + 8 * R * L * V)
         if q is not None:
-            entry('k_vechist', 'hbm', 12.0 * N * V + 8.0 * V * 2592, 1e9, PEAK_HBM_GBS, 'GB/s', None if fused_used else hist_ms, alone.get('hist'),
-                  formulation='one pass over the planes: rotation + Lambert histogram + mean vector + S2 sums; bytes = 12 N V + 8 V 2592 (SURVEY 8(d))'
-                              + ('; NOT part of the step any more (fused into k_pack_hist), timed alone for comparison' if fused_used else ''))
-        if alone.get('pack_hist'):
-            entry('k_pack_hist', 'hbm', 24.0 * s['frames'] * V + 8.0 * V * 2592, 1e9, PEAK_HBM_GBS, 'GB/s', hist_ms if fused_used else None, alone['pack_hist'],
-                  formulation='kernel 0 + kernel 2 fused (the step runs THIS, not the two entries below): one pass over the frame-major input writes the planes '
-                              'and the rotated Lambert histogram + mean-vector + S2 sums; bytes = 12 B read + 12 B written per (frame, vector) + 8 V 2592')
+            entry('k_vechist', 'hbm', 12.0 * N * V + 8.0 * V * 2592, 1e9, PEAK_HBM_GBS, 'GB/s', hist_ms, alone.get('hist'),
+                  formulation='one pass over the planes: rotation + Lambert histogram + mean vector + S2 sums; bytes = 12 N V + 8 V 2592 (SURVEY 8(d))')
         if alone.get('pack'):
             entry('k_pack_soa', 'hbm', 24.0 * s['frames'] * V, 1e9, PEAK_HBM_GBS, 'GB/s', None, alone['pack'],
-                  formulation='frame-major -> per-vector planes: 12 B read + 12 B written per (frame, vector)'
-                              + ('; NOT part of the step any more (fused into k_pack_hist), timed alone for comparison' if fused_used else ''))
+                  formulation='frame-major -> per-vector planes: 12 B read + 12 B written per (frame, vector)')
         if fit_ms is not None:
             pe = prof_entry(prof, 'k_order_search')
             fflop = pe.get('fp64_flop_per_launch') if pe else None
@@ -544,8 +534,6 @@ def main():
             kernels['k_order_search'] = e
         # the kernel that occupies most of the chip per batch
         off_step = {'k_ct_palmer'} if use_fft else set()
-        if fused_used:
-            off_step |= {'k_vechist', 'k_pack_soa'}
         ranked = sorted(((v.get('cu_ms_per_batch') or 0.0, k) for k, v in kernels.items() if k not in off_step), reverse=True)
         top = ranked[0][1] if ranked and ranked[0][0] > 0 else kname
         tk = kernels[top]

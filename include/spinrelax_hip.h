@@ -48,7 +48,10 @@ int          sr_sync(sr_ctx *);
  * all three cost the same per residue and 4 has the shortest launch (1.6x and 2.8x shorter than 2 and 1 on the
  * 512-residue benchmark batch); results are bit-identical only between runs with the same value), "fit_lds" = 1/0 keep
  * a residue's t, C(t), 1/sigma in LDS, "ct_fft" = formulation of kernel 1 where the chunk length allows: 2 (default) the
- * real-input FFT for 4096 < F + L <= 8192 and the complex FFT below, 1 the complex FFT everywhere, 0 always direct. */
+ * real-input FFT for 4096 < F + L <= 8192 and the complex FFT below, 1 the complex FFT everywhere, 0 always direct;
+ * "ct_traceless" = 1/0 (default 0): the real-input FFT kernel for F <= 4096 transforms the five traceless components of
+ * u (x) u and takes the trace term from a scan of |u|^2 - 1 (one transform fewer; series that are not unit vectors fall back
+ * to six inside the kernel) -- 4 % faster alone, 3 % slower per step inside the pipeline, same results to 1e-13. */
 int          sr_set_option(sr_ctx *, const char *name, int value);
 /* Streams that partition the chip.  The fits of fitting_Ct_functions.py:278-345 are a latency chain of small
  * launches; queued behind a C(t) launch that fills every CU they starve (queue priority does not pre-empt
@@ -145,20 +148,6 @@ int sr_rotate_hist_f32_dev(sr_ctx *, const float *soa, int64_t Npad, int64_t N, 
 int sr_rotate_hist_f32(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
                        const double *q, const double *edges_phi, int nphi, const double *edges_cos, int ncos,
                        double *hist, double *vecsum, double *outer, int64_t block_len);
-/* Kernel 0 and kernel 2 in ONE pass over the frame-major vectors: writes the planes sr_pack_soa_f32_dev writes (all Ntot
- * frames, zero-padded to Npad) and, from the same registers, what sr_rotate_hist_f32_dev computes -- histogram, vector sums
- * and per-block outer-product sums -- over
- *   chunk_start_host == NULL: the first N_hist frames, S2 blocks of block_len frames (0 = one block), or
- *   chunk_start_host != NULL: the R chunks [chunk_start[r], chunk_start[r] + block_len) of kernel 1 (ascending, not
- *                             overlapping: reformat_vecs_by_tau's used frames, calculate-Ct-from-traj.py:245-275); one S2
- *                             block per chunk, N_hist ignored.
- * Same arguments and results as the two calls it replaces (counts identical; the float64 sums are added in another order:
- * 1e-13).  Returns -6 when the histogram is too large for this kernel's LDS layout (more than ~2 600 bins): call the two
- * kernels then.  Uses context work areas: one stream at a time, like sr_rotate_hist_f32_dev. */
-int sr_pack_hist_f32_dev(sr_ctx *, const float *vecs, int64_t Ntot, int64_t Vtot, int64_t v0, int64_t nV, float *soa,
-                         int64_t Npad, int64_t N_hist, const int64_t *chunk_start_host, int64_t R, int64_t block_len,
-                         const double *q_host, const double *edges_phi_host, int nphi, const double *edges_cos_host, int ncos,
-                         double *hist, double *vecsum, double *outer);
 /* rotated vectors themselves, float64 (N, nV, 3) like the reference returns (for --vecDist output). */
 int sr_rotate_vectors_f32(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
                           const double *q, double *out);

@@ -55,8 +55,6 @@ SIGNATURES = {
                                        c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64]),
     'sr_rotate_hist_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int,
                                    c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64]),
-    'sr_pack_hist_f32_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
-                                     c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'sr_rotate_vectors_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     'sr_rotate_vectors_perframe_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     'sr_expfit_resjac_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

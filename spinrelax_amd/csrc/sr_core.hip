@@ -1,6 +1,5 @@
 // sr_core.hip -- context, device memory, stream and HIP-event timing of libspinrelax_hip.so
 #include "sr_internal.h"
-#include <cstdlib>
 #include <cstring>
 
 static thread_local char g_err[1024] = "";
@@ -63,6 +62,7 @@ sr_ctx *sr_create(int device)
     ctx->fit_waves = 4;
     ctx->fit_lds = 1;
     ctx->ct_fft = 2;
+    ctx->ct_traceless = 0;
     ctx->fft_table_ready = 0;
     if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) {
         sr_set_error("hipGetDeviceProperties failed");
@@ -91,7 +91,6 @@ void sr_destroy(sr_ctx *ctx)
         if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
-    free(ctx->tab_shadow);
     delete ctx;
 }
 
@@ -107,6 +106,11 @@ int sr_set_option(sr_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "ct_fft")) {
         SR_REQUIRE(value >= 0 && value <= 2, -3, "sr_set_option: ct_fft must be 0, 1 or 2");
         ctx->ct_fft = value;
+        return 0;
+    }
+    if (!strcmp(name, "ct_traceless")) {
+        SR_REQUIRE(value == 0 || value == 1, -3, "sr_set_option: ct_traceless must be 0 or 1");
+        ctx->ct_traceless = value;
         return 0;
     }
     if (!strcmp(name, "fit_lds")) {

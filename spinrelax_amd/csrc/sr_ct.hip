@@ -1245,23 +1245,18 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
 #undef SR_RFFT_LOAD1
 }
 
-// TR needs the whole series in the prologue's registers (3 planes x NZ pairs): the HALF variants
-template <int N1, bool HALF>
-constexpr bool rfft_use_tr() { return HALF; }
-template <int N1, bool HALF>
+template <int N1, bool HALF, bool TR>
 constexpr size_t rfft_lds_bytes()
 {
-    constexpr int NZ = HALF ? (N1 == 12 ? 8 : N1 / 2) : N1;
     // transform image + the 16 x 16 step-2 twiddles + the 256 step-1 twiddle bases (+ TR: the trace term's table Tt[0 .. 2048]
     // as float64, then 4 wave totals and 4 wave maxima)
-    return (size_t)(rfft_lds_slots(N1) + 512) * sizeof(cplx) + (rfft_use_tr<N1, HALF>() ? (size_t)(2 * 2056 + 16) * sizeof(float) : 0);
+    return (size_t)(rfft_lds_slots(N1) + 512) * sizeof(cplx) + (TR ? (size_t)(2 * 2056 + 16) * sizeof(float) : 0);
 }
 
-template <int N1, bool HALF>
+template <int N1, bool HALF, bool TR>
 int launch_ct_rfft_h(sr_ctx *ctx, const CtRfftArgs &a, int64_t series)
 {
-    constexpr bool TR = rfft_use_tr<N1, HALF>();
-    const size_t lds = rfft_lds_bytes<N1, HALF>();
+    const size_t lds = rfft_lds_bytes<N1, HALF, TR>();
     if (lds > 64 * 1024)
         SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ct_rfft<N1, HALF, TR>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1271,15 +1266,17 @@ int launch_ct_rfft_h(sr_ctx *ctx, const CtRfftArgs &a, int64_t series)
 }
 // With L = F/2 the two transform lengths are tied to the chunk length: M = 6144 serves 4096 < 1.5 F <= 6144, i.e. F <= 4096
 // (at most 8 of the 12 input blocks are non-zero: HALF), M = 8192 serves 4096 < F <= 5461 (more than half: not HALF).
-// Only those two instantiations exist.
+// Only those instantiations exist.  The traceless form of the M = 6144 kernel is an OPTION (sr_set_option "ct_traceless"):
+// alone it is 4 % faster (0.95 -> 0.915 ms for cfg3), inside the pipeline -- where a C(t) workgroup shares its CU with a
+// fit workgroup -- 3 % slower per step (same-box A/B), so the six-signal kernel stays the default.
 int launch_ct_rfft(sr_ctx *ctx, const CtRfftArgs &a, int64_t series)
 {
     if (a.F + a.L <= 6144) {
         SR_REQUIRE(a.F <= 4096, -3, "k_ct_rfft<12>: F=%d does not fit 8 input blocks", a.F);
-        return launch_ct_rfft_h<12, true>(ctx, a, series);
+        return ctx->ct_traceless ? launch_ct_rfft_h<12, true, true>(ctx, a, series) : launch_ct_rfft_h<12, true, false>(ctx, a, series);
     }
     SR_REQUIRE(a.F + a.L <= 8192, -3, "k_ct_rfft<16>: F=%d too long", a.F);
-    return launch_ct_rfft_h<16, false>(ctx, a, series);
+    return launch_ct_rfft_h<16, false, false>(ctx, a, series);
 }
 
 // mean / std over the R replicate chunks, calculate-Ct-from-traj.py:226-228.  One workgroup owns a tile of kFinV vectors x

@@ -7,7 +7,7 @@
 #include <cstring>
 #include "../../include/spinrelax_hip.h"
 
-#define SR_NSLOTS 16
+#define SR_NSLOTS 14
 
 struct sr_ctx {
     int device;
@@ -22,18 +22,14 @@ struct sr_ctx {
     int fit_lds;        // 1: stage t, y, 1/sigma of a residue in LDS when it fits; 0: read them from global memory
     int ct_fft;         // kernel 1 when the chunk length allows: 2 = real-input FFT for 4096 < F + L <= 8192 and complex FFT below
                         // (default), 1 = complex FFT formulation (k_ct_fft) everywhere, 0 = always the direct kernel
+    int ct_traceless;   // 1: k_ct_rfft<12> in its traceless five-signal form (faster alone, slower inside the pipeline: default 0)
     int fft_table_ready;
     // largest dynamic-LDS size already granted per kernel family (hipFuncSetAttribute is a per-DEVICE setting and a
     // context is bound to one device, so the cache lives here and not in a process-wide static)
     size_t lds_granted[8];
-    // host copy of the range table last uploaded to SR_WS_TAB (re-uploaded only when it changes: the upload is synchronous)
-    void *tab_shadow;
-    size_t tab_shadow_bytes;
-    // bytes copied host -> device by the entry points that take host vectors (sr_stats)
-    unsigned long long h2d_bytes;
 };
 
-enum { SR_K_CT1 = 0, SR_K_CT4, SR_K_VECHIST, SR_K_DQ, SR_K_MISC, SR_K_PACKHIST };
+enum { SR_K_CT1 = 0, SR_K_CT4, SR_K_VECHIST, SR_K_DQ, SR_K_MISC };
 
 enum {
     SR_WS_VECS = 0,     // staged host vectors (frame-major)
@@ -43,9 +39,7 @@ enum {
     SR_WS_IN0, SR_WS_IN1, SR_WS_IN2, SR_WS_IN3,
     SR_WS_MISC,
     SR_WS_FIT,          // residual work space of the fit kernel (when the caller passes none)
-    SR_WS_FFT,          // twiddle table of the FFT formulation of kernel 1
-    SR_WS_TAB,          // frame-range table of the fused pack + histogram kernel
-    SR_WS_HPART         // its per-range partial histograms
+    SR_WS_FFT           // twiddle table of the FFT formulation of kernel 1
 };
 
 void sr_set_error(const char *fmt, ...);

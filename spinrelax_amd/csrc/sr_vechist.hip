@@ -27,7 +27,6 @@
 // for 72x36) and is flushed with integer atomics (deterministic); the 9 float64 sums go to a
 // per-workgroup slot and are combined in fixed order by k_vechist_finalize (bitwise reproducible).
 #include "sr_internal.h"
-#include <cstdlib>
 
 namespace {
 
@@ -106,9 +105,7 @@ constexpr float kPhiGuardRad = 1.7e-5f, kCosGuard = 1.1e-5f;
 
 constexpr int kMaxRange = 8192;      // frames per range: bounds the LDS mask (1 KB) and list (16 KB) of undecided samples
 
-// exact (reference-order, float64) classification of one sample.  PK: two 16-bit counters per word (the fused pack +
-// histogram kernel keeps eight vectors' histograms in LDS; a workgroup never counts more than 65 535 samples)
-template <bool PK = false>
+// exact (reference-order, float64) classification of one sample
 __device__ __forceinline__ void vh_exact(const VhArgs &a, float xf, float yf, float zf, const double *ephi, const double *ecos,
                                          unsigned int *h)
 {
@@ -117,11 +114,7 @@ __device__ __forceinline__ void vh_exact(const VhArgs &a, float xf, float yf, fl
     if (a.rotate) rotate_q(a.qw, a.qx, a.qy, a.qz, x, y, z, rx, ry, rz);
     exact_phi_cos(rx, ry, rz, phi, c);
     const int kp = np_bin(ephi, a.nphi, phi), kc = np_bin(ecos, a.ncos, c);
-    if (kp >= 0 && kc >= 0) {
-        const int bin = kp * a.ncos + kc;
-        if (PK) atomicAdd(&h[bin >> 1], 1u << ((bin & 1) << 4));
-        else atomicAdd(&h[bin], 1u);
-    }
+    if (kp >= 0 && kc >= 0) atomicAdd(&h[kp * a.ncos + kc], 1u);
 }
 
 // atan2(y, x) in float32 without libm: octant reduction, one v_rcp_f32, a degree-7 polynomial in (min/max)^2 fitted to
@@ -152,7 +145,7 @@ __device__ __forceinline__ float fast_atan2f(float y, float x)
 // to its bin, an undecided one sets its bit (idx = its position in the range) in the LDS mask; the marked samples are
 // collected and classified exactly, one per thread, when the range has been streamed.  (Taken inline, the ~600-instruction
 // float64 path of one lane in ~300 would stall the other 63 lanes of its wave in one of six iterations.)
-template <bool ROT, bool INB, bool PK = false>
+template <bool ROT, bool INB>
 __device__ __forceinline__ void vh_sample(const VhArgs &a, float xf, float yf, float zf, unsigned int idx, unsigned int *h,
                                           unsigned int *mask, VhAcc &s, float phi_scale, float cos_scale, float hp, float hc)
 {
@@ -177,8 +170,8 @@ __device__ __forceinline__ void vh_sample(const VhArgs &a, float xf, float yf, f
     const bool sure = (int)(fabsf((tp - kpf) - 0.5f) < hp) & (int)(fabsf((tc - kcf) - 0.5f) < hc) & (int)(rxy2 > 4e-3f * r2) &
                       (int)(r2 > 1e-30f);
     const int bin = (int)kpf * a.ncos + (int)kcf;
-    unsigned int *addr = sure ? h + (PK ? bin >> 1 : bin) : mask + (idx >> 5);
-    atomicAdd(addr, sure ? (PK ? 1u << ((bin & 1) << 4) : 1u) : (1u << (idx & 31)));
+    unsigned int *addr = sure ? h + bin : mask + (idx >> 5);
+    atomicAdd(addr, sure ? 1u : (1u << (idx & 31)));
 }
 
 // The samples of one range, by ONE WAVE, through the fast classification (sums into s, decided samples into h, the others
@@ -345,12 +338,15 @@ struct VhRot {
     double R[3][3];
 };
 
-// per-range sums combined in fixed order, then rotated (see above)
-__device__ __forceinline__ void vh_finalize_sums(const double *__restrict__ partials, int64_t v, int64_t nV, int nranges, int nB,
-                                                 int m, const VhRot &rot, double *__restrict__ vecsum,
-                                                 double *__restrict__ outer, int tid)
+__global__ __launch_bounds__(256) void k_vechist_finalize(const unsigned int *__restrict__ hist_u32,
+                                                          const double *__restrict__ partials, int64_t nV, int nbins,
+                                                          int nranges, int nB, int m, VhRot rot, double *__restrict__ hist,
+                                                          double *__restrict__ vecsum, double *__restrict__ outer)
 {
 #pragma clang fp contract(off)
+    const int64_t v = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nbins; i += 256) hist[v * nbins + i] = (double)hist_u32[v * nbins + i];
     const double *p = partials + v * nranges * 9;
     if (vecsum && tid == 0) {
         double s[3] = {0.0, 0.0, 0.0};
@@ -373,245 +369,6 @@ __device__ __forceinline__ void vh_finalize_sums(const double *__restrict__ part
             o[0] = O[0][0]; o[1] = O[1][1]; o[2] = O[2][2]; o[3] = O[0][1]; o[4] = O[0][2]; o[5] = O[1][2];
         }
     }
-}
-
-__global__ __launch_bounds__(256) void k_vechist_finalize(const unsigned int *__restrict__ hist_u32,
-                                                          const double *__restrict__ partials, int64_t nV, int nbins,
-                                                          int nranges, int nB, int m, VhRot rot, double *__restrict__ hist,
-                                                          double *__restrict__ vecsum, double *__restrict__ outer)
-{
-    const int64_t v = blockIdx.x;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < nbins; i += 256) hist[v * nbins + i] = (double)hist_u32[v * nbins + i];
-    vh_finalize_sums(partials, v, nV, nranges, nB, m, rot, vecsum, outer, tid);
-}
-
-// ------------------------------------------------------------------------------------------
-// kernel 0 + kernel 2 in ONE pass over the frame-major input: per-vector planes (what k_pack_soa writes) AND the rotated
-// Lambert histogram, mean-vector and S2 sums (what k_vechist computes from the planes).  The planes are then only read by
-// kernel 1: 615 MB of HBM reads and one launch per batch less.
-//
-// A workgroup owns kPhVec = 8 consecutive vectors and one frame range (<= kMaxRange frames, inside one S2 block): eight
-// histograms live in LDS as packed 16-bit counters (8 x 2592 x 2 B = 41 KB), so a range's counts need no global atomics
-// at all -- they leave as one coalesced store of the packed words and k_packhist_finalize adds the ranges up (+128 MB of
-// traffic against 615 MB saved; device-scope atomics run at the memory side, ~2e10/s for scattered words: the ~2e6 non-
-// empty (range, vector, bin) cells would cost more than the pass itself).
-// Reads: a lane loads one sample (12 bytes, x y z of one vector in one frame); a wave covers 8 frames x 8 vectors = eight
-// 96-byte runs.  Four neighbouring vector groups share the three 128-byte lines of a frame row; their workgroups are
-// dealt to the SAME XCD back to back (blockIdx -> item mapping below; blocks b and b + 8 share an XCD), so the lines
-// are fetched from HBM once and served from that XCD's L2 to the other three.  Classification happens on the sample while
-// it is in registers (the fast float32 path of k_vechist, undecided samples parked in a bit mask and classified
-// exactly afterwards from the input array); the samples then go through the wave's own LDS tile (8 vectors x 3 components x
-// 64 frames) and out to the planes as 16-byte stores.  No workgroup barrier while streaming: every wave runs its own
-// software-pipelined loop (first version: one 256-frame tile per workgroup, two barriers per tile, loads not overlapped
-// with anything -- 0.55 ms against 0.23 + 0.18 ms for the two kernels it replaces).
-// ------------------------------------------------------------------------------------------
-constexpr int kPhVec = 8;
-constexpr int kPhTile = 64;               // frames per wave tile
-constexpr int kPhRow = kPhTile + 4;        // floats per tile row: the 64 lanes of a column write hit 32 different banks
-
-struct PhRange {
-    long long start;                       // first frame
-    int len;                               // frames (1 .. kMaxRange)
-    int rid;                               // histogram range index (layout of VhArgs::partials), -1 = pack only
-    int inb;                               // 1: inside an S2 block (all nine sums), 0: tail (vector sums only)
-    int pad;
-};
-
-struct PhArgs {
-    VhArgs vh;                             // rotation, edges, nphi / ncos (soa / N / ranges of VhArgs unused)
-    const float *vecs;                     // (Ntot, Vtot, 3)
-    int64_t Ntot, Vtot, v0, nV;
-    float *soa;                            // (nV, 3, Npad)
-    int64_t Npad;
-    const PhRange *ranges;
-    int nitems, ngroups, nhist, nbw;       // nitems = ranges x (ngroups / 4); ngroups = vector groups, padded to 4
-    unsigned int *hist_part;               // (nhist, nV, nbw) packed 16-bit counter pairs
-};
-
-__global__ __launch_bounds__(256, 2) void k_pack_hist(PhArgs a)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    const VhArgs &vh = a.vh;
-    const int ne = vh.nphi + 1 + vh.ncos + 1;
-    double *edges = reinterpret_cast<double *>(smem);
-    double *wsum = edges + ((ne + 1) & ~1);                                         // 4 waves x 8 vectors x 9 sums
-    unsigned int *h = reinterpret_cast<unsigned int *>(wsum + 4 * kPhVec * 9);       // kPhVec x nbw4 packed counters
-    const int nbw4 = (a.nbw + 3) & ~3;
-    unsigned int *mask = h + kPhVec * nbw4;                                          // kPhVec x kMaxRange bits
-    float *tile = reinterpret_cast<float *>(mask + kPhVec * (kMaxRange / 32));       // per wave: 3 kPhVec rows of kPhRow floats
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-
-    // item of this workgroup: the four vector groups of a quad (same frame range) sit in consecutive slots of one XCD
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int it = (slot >> 2) * 8 + xcd;
-    if (it >= a.nitems) return;
-    const int nquads = a.ngroups >> 2;
-    const int ridx = it / nquads, grp = (it - ridx * nquads) * 4 + (slot & 3);
-    const int64_t vb = (int64_t)grp * kPhVec;                     // first vector of the group, relative to v0
-    if (vb >= a.nV) return;
-    const int nvec = (int)min((int64_t)kPhVec, a.nV - vb);
-    const PhRange rg = a.ranges[ridx];
-    const bool do_hist = rg.rid >= 0;
-
-    for (int i = tid; i < ne; i += 256) edges[i] = vh.edges ? vh.edges[i] : vh.edges_inline[i];
-    for (int i = tid; i < kPhVec * nbw4; i += 256) h[i] = 0u;
-    for (int i = tid; i < kPhVec * (kMaxRange / 32); i += 256) mask[i] = 0u;
-    __syncthreads();
-    const double *ephi = edges, *ecos = edges + vh.nphi + 1;
-    const float phi_scale = (float)((double)vh.nphi / (ephi[vh.nphi] - ephi[0]));
-    const float cos_scale = (float)((double)vh.ncos / (ecos[vh.ncos] - ecos[0]));
-    const float hp = 0.5f - fmaxf(kEdgeGuard, kPhiGuardRad * phi_scale), hc = 0.5f - fmaxf(kEdgeGuard, kCosGuard * cos_scale);
-
-    // Every WAVE streams its own 64-frame tiles (tile w, w + 4, ... of the range) without a workgroup barrier: loads of the
-    // next tile in flight (24 registers) while the current one is classified, staged through the wave's private LDS tile
-    // (8 vectors x 3 components x 64 frames) and written to the planes.  LDS operations of one wave complete in order, so
-    // the staging needs fences for the compiler only.
-    const int vl = lane & 7, fl = lane >> 3;                      // this lane's vector of the group and frame of a pass
-    const bool vok = vl < nvec;
-    const float *src = a.vecs + (a.v0 + vb + (vok ? vl : 0)) * 3;
-    unsigned int *hv = h + vl * nbw4, *mv = mask + vl * (kMaxRange / 32);
-    float *wtile = tile + wave * (3 * kPhVec * kPhRow);
-    float *trow = wtile + (vl * 3) * kPhRow;
-    VhAcc s = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int64_t end = rg.start + rg.len;
-    const bool aligned = ((rg.start | a.Npad) & 3) == 0;          // 16-byte plane stores
-    const int ntiles = (rg.len + kPhTile - 1) / kPhTile;
-    float XA[8], YA[8], ZA[8], XB[8], YB[8], ZB[8];
-    // all 24 loads of a tile (unconditional, from a clamped frame: a conditional load is a branch per sample)
-#define SR_PH_LOAD(T, X, Y, Z)                                                                   \
-    {                                                                                            \
-        const int64_t t0_ = rg.start + (int64_t)(T) * kPhTile;                                   \
-        _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                          \
-            const int64_t fr = t0_ + p * 8 + fl;                                                 \
-            const bool ok = vok && fr < end && fr < a.Ntot;                                      \
-            const float *q = src + (ok ? fr : 0) * a.Vtot * 3;                                   \
-            const float x = q[0], y = q[1], z = q[2];                                            \
-            X[p] = ok ? x : 0.f; Y[p] = ok ? y : 0.f; Z[p] = ok ? z : 0.f;                       \
-        }                                                                                        \
-    }
-#define SR_PH_TILE(T, X, Y, Z)                                                                   \
-    {                                                                                            \
-        const int64_t t0 = rg.start + (int64_t)(T) * kPhTile;                                    \
-        const int tl = (int)min((int64_t)kPhTile, end - t0);                                     \
-        _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                          \
-            const int o = p * 8 + fl;                                                            \
-            const bool ok = vok && o < tl && t0 + o < a.Ntot;                                    \
-            if (do_hist && ok) {                                                                 \
-                const unsigned int idx = (unsigned int)(t0 - rg.start) + (unsigned int)o;        \
-                if (vh.rotate) {                                                                 \
-                    if (rg.inb) vh_sample<true, true, true>(vh, X[p], Y[p], Z[p], idx, hv, mv, s, phi_scale, cos_scale, hp, hc);  \
-                    else vh_sample<true, false, true>(vh, X[p], Y[p], Z[p], idx, hv, mv, s, phi_scale, cos_scale, hp, hc);       \
-                } else {                                                                         \
-                    if (rg.inb) vh_sample<false, true, true>(vh, X[p], Y[p], Z[p], idx, hv, mv, s, phi_scale, cos_scale, hp, hc); \
-                    else vh_sample<false, false, true>(vh, X[p], Y[p], Z[p], idx, hv, mv, s, phi_scale, cos_scale, hp, hc);      \
-                }                                                                                \
-            }                                                                                    \
-            trow[o] = X[p];                                                                      \
-            trow[kPhRow + o] = Y[p];                                                             \
-            trow[2 * kPhRow + o] = Z[p];                                                         \
-        }                                                                                        \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                   \
-        __builtin_amdgcn_wave_barrier();                                                         \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                   \
-        /* planes: row k = (vector, component) of the group, 16 groups of four frames per row */ \
-        _Pragma("unroll") for (int j = 0; j < 3 * kPhVec * (kPhTile / 4) / 64; ++j) {            \
-            const int idx = lane + 64 * j;                                                       \
-            const int k = idx >> 4, q4 = (idx & 15) * 4;                                         \
-            if (k < nvec * 3 && q4 < tl) {                                                       \
-                const float4 val = *reinterpret_cast<const float4 *>(wtile + k * kPhRow + q4);  \
-                float *dst = a.soa + (vb * 3 + k) * a.Npad + t0 + q4;                            \
-                if (aligned && q4 + 3 < tl) {                                                    \
-                    *reinterpret_cast<float4 *>(dst) = val;                                      \
-                } else {                                                                         \
-                    const float e[4] = {val.x, val.y, val.z, val.w};                             \
-                    for (int u = 0; u < 4 && q4 + u < tl; ++u) dst[u] = e[u];                    \
-                }                                                                                \
-            }                                                                                    \
-        }                                                                                        \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                   \
-        __builtin_amdgcn_wave_barrier();                                                         \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                   \
-    }
-    if (wave < ntiles) {
-        SR_PH_LOAD(wave, XA, YA, ZA)
-        for (int t = wave; t < ntiles; t += 8) {
-            if (t + 4 < ntiles) SR_PH_LOAD(t + 4, XB, YB, ZB)
-            SR_PH_TILE(t, XA, YA, ZA)
-            if (t + 4 < ntiles) {
-                if (t + 8 < ntiles) SR_PH_LOAD(t + 8, XA, YA, ZA)
-                SR_PH_TILE(t + 4, XB, YB, ZB)
-            }
-        }
-    }
-#undef SR_PH_LOAD
-#undef SR_PH_TILE
-    __syncthreads();
-    if (!do_hist) return;
-
-    // the nine sums: lanes lane, lane ^ 8, ^ 16, ^ 32 hold the same vector; then the four waves in fixed order
-    {
-        double vals[9] = {s.sx, s.sy, s.sz, s.oxx, s.oyy, s.ozz, s.oxy, s.oxz, s.oyz};
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            double t = vals[k];
-            t += __shfl_xor(t, 8, 64);
-            t += __shfl_xor(t, 16, 64);
-            t += __shfl_xor(t, 32, 64);
-            if (lane < kPhVec) wsum[(wave * kPhVec + lane) * 9 + k] = t;
-        }
-    }
-    __syncthreads();                                              // also: every sample of the range is counted or marked
-    if (tid < kPhVec * 9) {
-        const int v8 = tid / 9, k = tid - v8 * 9;
-        if (v8 < nvec) {
-            const double t = ((wsum[(0 * kPhVec + v8) * 9 + k] + wsum[(1 * kPhVec + v8) * 9 + k]) + wsum[(2 * kPhVec + v8) * 9 + k]) +
-                             wsum[(3 * kPhVec + v8) * 9 + k];
-            vh.partials[((vb + v8) * vh.nranges + rg.rid) * 9 + k] = t;
-        }
-    }
-    // undecided samples: exact classification from the input array
-    {
-        const int wpr = (rg.len + 31) >> 5;                       // mask words per vector in use
-        for (int wi = tid; wi < nvec * wpr; wi += 256) {
-            const int v8 = wi / wpr, w0 = wi - v8 * wpr;
-            unsigned int bits = mask[v8 * (kMaxRange / 32) + w0];
-            while (bits) {
-                const int bpos = __ffs((int)bits) - 1;
-                bits &= bits - 1u;
-                const int64_t fr = rg.start + w0 * 32 + bpos;
-                const float *q = a.vecs + (fr * a.Vtot + a.v0 + vb + v8) * 3;
-                vh_exact<true>(vh, q[0], q[1], q[2], ephi, ecos, h + v8 * nbw4);
-            }
-        }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < nvec * a.nbw; idx += 256) {
-        const int v8 = idx / a.nbw, i = idx - v8 * a.nbw;
-        a.hist_part[((int64_t)rg.rid * a.nV + vb + v8) * a.nbw + i] = h[v8 * nbw4 + i];
-    }
-}
-
-// histogram = sum over the ranges of the packed 16-bit counters; sums as in k_vechist_finalize
-__global__ __launch_bounds__(256) void k_packhist_finalize(const unsigned int *__restrict__ hist_part,
-                                                           const double *__restrict__ partials, int64_t nV, int nbins, int nbw,
-                                                           int nranges, int nB, int m, VhRot rot, double *__restrict__ hist,
-                                                           double *__restrict__ vecsum, double *__restrict__ outer)
-{
-    const int64_t v = blockIdx.x;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < nbw; i += 256) {
-        unsigned int lo = 0u, hi = 0u;
-        for (int r = 0; r < nranges; ++r) {
-            const unsigned int w = hist_part[((int64_t)r * nV + v) * nbw + i];
-            lo += w & 0xFFFFu;
-            hi += w >> 16;
-        }
-        hist[v * nbins + 2 * i] = (double)lo;
-        if (2 * i + 1 < nbins) hist[v * nbins + 2 * i + 1] = (double)hi;
-    }
-    vh_finalize_sums(partials, v, nV, nranges, nB, m, rot, vecsum, outer, tid);
 }
 
 // rotated vectors themselves: (N, Vtot, 3) float32 slice -> (N, nV, 3) float64
@@ -732,154 +489,6 @@ int sr_rotate_hist_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64_t 
     SR_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_vechist_finalize, dim3((unsigned)nV), dim3(256), 0, ctx->stream, h32, partials, nV, nbins,
                        a.nranges, a.nB, a.m, rot, hist, vecsum, outer);
-    SR_HIP(hipGetLastError());
-    return 0;
-}
-
-int sr_pack_hist_f32_dev(sr_ctx *ctx, const float *vecs, int64_t Ntot, int64_t Vtot, int64_t v0, int64_t nV, float *soa,
-                         int64_t Npad, int64_t N_hist, const int64_t *chunk_start_host, int64_t R, int64_t block_len,
-                         const double *q_host, const double *edges_phi_host, int nphi, const double *edges_cos_host, int ncos,
-                         double *hist, double *vecsum, double *outer)
-{
-    SR_CHECK_CTX(ctx);
-    SR_REQUIRE(vecs && soa && hist && edges_phi_host && edges_cos_host, -2, "sr_pack_hist_f32_dev: null pointer");
-    SR_REQUIRE(Ntot > 0 && Vtot > 0 && nV > 0 && v0 >= 0 && v0 + nV <= Vtot, -3,
-               "sr_pack_hist_f32_dev: bad shape Ntot=%lld Vtot=%lld v0=%lld nV=%lld", (long long)Ntot, (long long)Vtot,
-               (long long)v0, (long long)nV);
-    SR_REQUIRE(Npad >= Ntot && Npad % 4 == 0, -3, "sr_pack_hist_f32_dev: Npad=%lld must be >= Ntot and a multiple of 4",
-               (long long)Npad);
-    SR_REQUIRE(nphi >= 1 && ncos >= 1 && nphi + ncos + 2 <= kInlineEdges, -6,
-               "sr_pack_hist_f32_dev: %d x %d bins: use sr_pack_soa_f32_dev + sr_rotate_hist_f32_dev", nphi, ncos);
-    const int nbins = nphi * ncos, nbw = (nbins + 1) / 2, nbw4 = (nbw + 3) & ~3;
-    const int ne = nphi + 1 + ncos + 1;
-    const size_t lds = (size_t)((ne + 1) & ~1) * sizeof(double) + (size_t)4 * kPhVec * 9 * sizeof(double) +
-                       (size_t)kPhVec * nbw4 * sizeof(unsigned int) + (size_t)kPhVec * (kMaxRange / 32) * sizeof(unsigned int) +
-                       (size_t)4 * 3 * kPhVec * kPhRow * sizeof(float);
-    SR_REQUIRE(lds <= sr_lds_limit(ctx) / 2, -6,
-               "sr_pack_hist_f32_dev: %d x %d bins need %zu B of LDS per workgroup (two must share a CU): use sr_pack_soa_f32_dev + "
-               "sr_rotate_hist_f32_dev", nphi, ncos, lds);
-    // ---- blocks (S2 blocks = the chunks of kernel 1 when chunk starts are given) and their frame ranges ----
-    int64_t Fb, nB;
-    if (chunk_start_host) {
-        SR_REQUIRE(R >= 1 && block_len >= 1, -3, "sr_pack_hist_f32_dev: chunk starts need R >= 1 and block_len = frames per chunk");
-        Fb = block_len; nB = R;
-        for (int64_t r = 0; r < R; ++r)
-            SR_REQUIRE(chunk_start_host[r] >= 0 && chunk_start_host[r] + Fb <= Ntot && (r == 0 || chunk_start_host[r] >= chunk_start_host[r - 1] + Fb),
-                       -3, "sr_pack_hist_f32_dev: chunk %lld start %lld out of range or overlapping", (long long)r, (long long)chunk_start_host[r]);
-    } else {
-        SR_REQUIRE(N_hist >= 1 && N_hist <= Ntot, -3, "sr_pack_hist_f32_dev: N_hist=%lld out of range", (long long)N_hist);
-        Fb = (block_len > 0 && block_len <= N_hist) ? block_len : N_hist;
-        nB = N_hist / Fb;
-    }
-    const int64_t ngroups = sr_round_up((nV + kPhVec - 1) / kPhVec, 4);
-    // ranges per block: enough workgroups to fill the chip (>= ~1024), each at least 1024 and at most kMaxRange frames
-    int64_t m = (1024 + nB * ngroups - 1) / (nB * ngroups);
-    const int64_t maxm = (Fb + 1023) / 1024, minm = (Fb + kMaxRange - 1) / kMaxRange;
-    if (m > maxm) m = maxm;
-    if (m < minm) m = minm;
-    int64_t sub = sr_round_up((Fb + m - 1) / m, 4);
-    if (sub > kMaxRange) sub = kMaxRange;
-    m = (Fb + sub - 1) / sub;
-    const int64_t tail = chunk_start_host ? 0 : N_hist - nB * Fb;
-    const int64_t ntail = (tail + sub - 1) / sub;
-    const int64_t nhist = nB * m + ntail;
-    // table: histogram ranges first (their index is the slot of VhArgs::partials), then whatever else must reach the planes
-    const int64_t psub = 4096;                // frames per pack-only range
-    const size_t cap = (size_t)(nhist + Npad / psub + 2 * nB + 8);
-    PhRange *tab = (PhRange *)calloc(cap, sizeof(PhRange));
-    SR_REQUIRE(tab != nullptr, -5, "sr_pack_hist_f32_dev: out of host memory");
-    size_t nr = 0;
-    int64_t covered = 0;                      // frames [0, covered) are in the table
-    auto pack_only = [&](int64_t from, int64_t to) {
-        for (int64_t f = from; f < to && nr < cap; f += psub) {
-            tab[nr].start = f; tab[nr].len = (int)(to - f < psub ? to - f : psub); tab[nr].rid = -1; tab[nr].inb = 0; ++nr;
-        }
-    };
-    size_t nh = 0;
-    {
-        // first pass: histogram ranges in slot order; second pass appends the gaps
-        for (int64_t b = 0; b < nB; ++b) {
-            const int64_t bs = chunk_start_host ? chunk_start_host[b] : b * Fb;
-            for (int64_t i = 0; i < m; ++i) {
-                const int64_t st = bs + i * sub, en = st + sub < bs + Fb ? st + sub : bs + Fb;
-                tab[nr].start = st; tab[nr].len = (int)(en - st); tab[nr].rid = (int)(b * m + i); tab[nr].inb = 1; ++nr;
-            }
-        }
-        for (int64_t i = 0; i < ntail; ++i) {
-            const int64_t st = nB * Fb + i * sub, en = st + sub < N_hist ? st + sub : N_hist;
-            tab[nr].start = st; tab[nr].len = (int)(en - st); tab[nr].rid = (int)(nB * m + i); tab[nr].inb = 0; ++nr;
-        }
-        nh = nr;
-        for (int64_t b = 0; b < nB; ++b) {
-            const int64_t bs = chunk_start_host ? chunk_start_host[b] : b * Fb;
-            if (bs > covered) pack_only(covered, bs);
-            covered = bs + Fb;
-        }
-        if (!chunk_start_host) covered = N_hist;
-        if (covered < Npad) pack_only(covered, Npad);
-    }
-    if (nr >= cap || (int64_t)nh != nhist) {
-        free(tab);
-        sr_set_error("sr_pack_hist_f32_dev: internal range table error");
-        return -9;
-    }
-    const size_t tab_bytes = nr * sizeof(PhRange);
-    PhRange *tab_d = (PhRange *)sr_workspace(ctx, SR_WS_TAB, tab_bytes);
-    unsigned int *hpart = (unsigned int *)sr_workspace(ctx, SR_WS_HPART, (size_t)nhist * nV * nbw * sizeof(unsigned int));
-    double *partials = (double *)sr_workspace(ctx, SR_WS_OUT3, (size_t)nV * nhist * 9 * sizeof(double));
-    if (!tab_d || !hpart || !partials) { free(tab); return -5; }
-    if (ctx->tab_shadow_bytes != tab_bytes || memcmp(ctx->tab_shadow, tab, tab_bytes) != 0) {
-        // new geometry: synchronous upload (rare: a pipeline repeats the same table batch after batch)
-        hipError_t e1 = hipStreamSynchronize(ctx->stream);
-        hipError_t e2 = hipMemcpy(tab_d, tab, tab_bytes, hipMemcpyHostToDevice);
-        if (e1 != hipSuccess || e2 != hipSuccess) {
-            free(tab);
-            sr_set_error("sr_pack_hist_f32_dev: range table upload failed");
-            return -100;
-        }
-        free(ctx->tab_shadow);
-        ctx->tab_shadow = tab;
-        ctx->tab_shadow_bytes = tab_bytes;
-    } else {
-        free(tab);
-    }
-    PhArgs a;
-    memset(&a, 0, sizeof(a));
-    VhArgs &vh = a.vh;
-    vh.nphi = nphi; vh.ncos = ncos; vh.nranges = (int)nhist; vh.nB = (int)nB; vh.m = (int)m;
-    vh.rotate = q_host ? 1 : 0;
-    vh.qw = 1; vh.qx = vh.qy = vh.qz = 0;
-    if (q_host) {
-        double qn[4];
-        normalise_q(q_host, qn);
-        vh.qw = qn[0]; vh.qx = qn[1]; vh.qy = qn[2]; vh.qz = qn[3];
-    }
-    VhRot rot;
-    {
-        const double w = vh.qw, x = vh.qx, y = vh.qy, z = vh.qz;
-        const double Rm[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
-                                 {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
-                                 {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                rot.R[i][j] = vh.rotate ? Rm[i][j] : (i == j ? 1.0 : 0.0);
-                vh.rm[i * 3 + j] = (float)rot.R[i][j];
-            }
-    }
-    for (int i = 0; i <= nphi; ++i) vh.edges_inline[i] = edges_phi_host[i];
-    for (int i = 0; i <= ncos; ++i) vh.edges_inline[nphi + 1 + i] = edges_cos_host[i];
-    vh.edges = nullptr;
-    vh.partials = partials;
-    a.vecs = vecs; a.Ntot = Ntot; a.Vtot = Vtot; a.v0 = v0; a.nV = nV; a.soa = soa; a.Npad = Npad;
-    a.ranges = tab_d; a.ngroups = (int)ngroups; a.nitems = (int)(nr * (size_t)(ngroups / 4)); a.nhist = (int)nhist; a.nbw = nbw;
-    a.hist_part = hpart;
-    if (int rc = sr_grant_lds(ctx, SR_K_PACKHIST, reinterpret_cast<const void *>(&k_pack_hist), lds)) return rc;
-    const int64_t nblocks = sr_round_up(a.nitems, 8) * 4;
-    SR_REQUIRE(nblocks < ((int64_t)1 << 31), -3, "sr_pack_hist_f32_dev: too many workgroups");
-    hipLaunchKernelGGL(k_pack_hist, dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, a);
-    SR_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_packhist_finalize, dim3((unsigned)nV), dim3(256), 0, ctx->stream, hpart, partials, nV, nbins, nbw,
-                       (int)nhist, (int)nB, (int)m, rot, hist, vecsum, outer);
     SR_HIP(hipGetLastError());
     return 0;
 }

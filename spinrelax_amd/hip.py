@@ -193,22 +193,6 @@ class Context:
                                               ec.size - 1, hist_ptr, vecsum_ptr, outer_ptr, int(block_len or 0)),
               'sr_rotate_hist_f32_dev')
 
-    def pack_hist_dev(self, vecs_ptr, Ntot, Vtot, v0, nV, soa_ptr, Npad, N_hist, q, edges_phi, edges_cos, hist_ptr, vecsum_ptr,
-                      outer_ptr, block_len, chunk_start=None):
-        """kernel 0 + kernel 2 in one pass (sr_pack_hist_f32_dev); returns False when the histogram does not fit that kernel's
-        LDS layout (the caller then packs and histograms separately)"""
-        ep = _f64(edges_phi)
-        ec = _f64(edges_cos)
-        qq = None if q is None else _f64(q)
-        cs = None if chunk_start is None else np.ascontiguousarray(chunk_start, dtype=np.int64)
-        rc = self.lib.sr_pack_hist_f32_dev(self.h, vecs_ptr, Ntot, Vtot, v0, nV, soa_ptr, Npad, N_hist, _ptr(cs),
-                                           0 if cs is None else cs.size, int(block_len or 0), _ptr(qq), _ptr(ep), ep.size - 1,
-                                           _ptr(ec), ec.size - 1, hist_ptr, vecsum_ptr, outer_ptr)
-        if rc == -6:
-            return False
-        check(rc, 'sr_pack_hist_f32_dev')
-        return True
-
     def rotate_vectors(self, vecs, q, v0=0, nV=None):
         """q: (4,) one rotation for everything, or (N, 4) one UNIT quaternion per frame."""
         vecs = _f32(vecs)

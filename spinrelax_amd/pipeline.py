@@ -120,8 +120,7 @@ class _Slot:
 class DevicePipeline:
     def __init__(self, ctx, device, frames, V, R, F, dt, q_rot=None, Diso=None, aniso=None, field_MHz=(600.133,),
                  zeta=0.890023, histBinX=72, listDoG=(2, 3, 5, 7, 9), csa=None, depth=1, stream=None, reserve_cus=0,
-                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None, hist_on_aux=True, v0=0, aux_cus=0, fit_priority=0, plane_buffers=3,
-                 fuse_pack_hist=False):
+                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None, hist_on_aux=True, v0=0, aux_cus=0, fit_priority=0, plane_buffers=3):
         self.ctx = ctx
         self.dev = device
         self.frames, self.V, self.R, self.F, self.dt = frames, V, R, F, dt
@@ -190,16 +189,6 @@ class DevicePipeline:
         self.aux = (self._borrow(aux_words) if aux_words is not None else torch.cuda.Stream(device=device)) if self.depth > 1 else None
         self._packed_ev = [None] * self.NB
         self.hist_on_aux = hist_on_aux
-        # Fused pack + histogram (one pass over the input, sr_pack_hist_f32_dev) unless the per-frame de-tumbling pack is in
-        # use.  The histogram of batch k is then written while batch k is PACKED, i.e. one batch ahead of the slot rotation:
-        # its buffers come from a pool of depth + 2 entries indexed by the batch number, so that the pack never has to wait
-        # for the batch that used a slot before (whose relaxation kernel reads its histogram until it is done).
-        self.fused = fuse_pack_hist and q_orient is None
-        self._hist_pool = [(sl.hist, sl.vecsum, sl.outer) for sl in self.slots]
-        if self.fused and self.depth > 1:
-            for _ in range(2):
-                self._hist_pool.append(tuple(torch.empty_like(t) for t in self._hist_pool[0]))
-        self._hist_guard = [None] * len(self._hist_pool)
         # Consecutive C(t) launches alternate between two streams (one per plane buffer): the next grid's workgroups fill the
         # slots the previous grid's last, partially filled round leaves (a twelfth of a launch) and its launch latency
         # (~0.15 ms between two 12 288-workgroup kernels on one stream) disappears behind it.
@@ -310,15 +299,6 @@ class DevicePipeline:
         else:
             self.ctx.pack_soa_dev(vecs.data_ptr(), self.frames, vecs.shape[1], self.v0, self.V, soa.data_ptr(), self.Npad)
 
-    def stage_pack_hist(self, vecs, bufs, soa=None):
-        """kernel 0 + kernel 2 in one pass over the frame-major vectors (planes for C(t); histogram, vector sums and S2 sums
-        into bufs = (hist, vecsum, outer)); False when the library cannot fuse them for this histogram size"""
-        soa = self.soa if soa is None else soa
-        hist, vecsum, outer = bufs
-        return self.ctx.pack_hist_dev(vecs.data_ptr(), self.frames, vecs.shape[1], self.v0, self.V, soa.data_ptr(), self.Npad,
-                                      self.N, self.q, self.edges[0], self.edges[1], hist.data_ptr(), vecsum.data_ptr(),
-                                      outer.data_ptr(), self.F)
-
     def stage_ct(self, s=None, soa=None, mid_event=None, finalize=True):
         """C(t): raw sums (the dominant kernel), then mean / std over the chunks.  mid_event is recorded between the two."""
         s = s or self.slots[0]
@@ -333,11 +313,6 @@ class DevicePipeline:
         """mean / std over the chunks, written in both orientations by one launch: (L, V) as the reference holds C(t) and
         (V, L) for the fits (stage_transpose is only needed behind a finalize that did not write them)"""
         s = s or self.slots[0]
-        import os
-        if os.environ.get('SR_DEV_OLD_FINALIZE'):
-            self.ctx.ct_finalize_dev(s.psum.data_ptr(), self.R, self.F, self.V, s.Ct.data_ptr(), s.dCt.data_ptr())
-            self.stage_transpose(s)
-            return
         self.ctx.ct_finalize_dev(s.psum.data_ptr(), self.R, self.F, self.V, s.Ct.data_ptr(), s.dCt.data_ptr(),
                                  s.CtT.data_ptr(), s.dCtT.data_ptr())
 
@@ -390,30 +365,18 @@ class DevicePipeline:
         events: [before the C(t) kernel, after it (before its finalize), before histogram, after histogram, (4, 5: see
         back())]; the first two on the main stream."""
         s = self.slots[k % self.depth]
-        if self.fused and self.aux is not None:
-            return self._front_fused(vecs, k, events, pack_next)
         if self.aux is None:
             self.ctx.set_stream(self.main.cuda_stream)
             with torch.cuda.stream(self.main):
-                if self.fused:
-                    if events is not None:
-                        events[2].record(self.main)
-                    fused_ok = self.stage_pack_hist(vecs, (s.hist, s.vecsum, s.outer))
-                    if events is not None:
-                        events[3].record(self.main)
-                    if not fused_ok:
-                        self.fused = False
-                if not self.fused:
-                    self.stage_pack(vecs)
+                self.stage_pack(vecs)
                 if events is not None:
                     events[0].record(self.main)
                 self.stage_ct(s, mid_event=None if events is None else events[1])
-                if not self.fused:
-                    if events is not None:
-                        events[2].record(self.main)
-                    self.stage_hist(s)
-                    if events is not None:
-                        events[3].record(self.main)
+                if events is not None:
+                    events[2].record(self.main)
+                self.stage_hist(s)
+                if events is not None:
+                    events[3].record(self.main)
                 s.front_done = torch.cuda.Event()
                 s.front_done.record(self.main)
                 s.hist_done = s.front_done
@@ -480,57 +443,6 @@ class DevicePipeline:
                     events[3].record(self.aux)
                 s.hist_done = torch.cuda.Event()
                 s.hist_done.record(self.aux)
-        self.ctx.set_stream(self.main.cuda_stream)
-        return s
-
-    def _front_fused(self, vecs, k, events, pack_next):
-        """Overlapped throughput half with the fused pack + histogram kernel: C(t) of batch k on the (alternating) main
-        streams; on the auxiliary stream the pack + histogram of batch k + 1 (`pack_next`), one batch ahead.  events as in
-        front(); [2] and [3] bracket the fused launch issued here (the next batch's)."""
-        D, NB, P = self.depth, self.NB, len(self._hist_pool)
-        s = self.slots[k % D]
-        b = k % NB
-        buf = self.soa_bufs[b]
-
-        def pack_hist(vv, kk, ev=None):
-            nb = kk % NB
-            hi = kk % P
-            self.ctx.set_stream(self.aux.cuda_stream)
-            with torch.cuda.stream(self.aux):
-                if self._ct_done_ev[nb] is not None:
-                    self.aux.wait_event(self._ct_done_ev[nb])       # C(t) of batch kk - NB has read that plane buffer
-                if self._hist_guard[hi] is not None:
-                    self.aux.wait_event(self._hist_guard[hi])       # a device-side reader of batch kk - P's histogram
-                    self._hist_guard[hi] = None
-                if ev is not None:
-                    ev[2].record(self.aux)
-                if not self.stage_pack_hist(vv, self._hist_pool[hi], self.soa_bufs[nb]):
-                    raise RuntimeError('fused pack + histogram not available for this histogram size: build the pipeline with fuse_pack_hist=False')
-                if ev is not None:
-                    ev[3].record(self.aux)
-                self._packed_ev[nb] = torch.cuda.Event()
-                self._packed_ev[nb].record(self.aux)
-
-        if not self._packed:
-            pack_hist(vecs, k)                 # first batch of a run: nothing was packed ahead
-        self._packed = False
-        s.hist, s.vecsum, s.outer = self._hist_pool[k % P]
-        main = self.main_alt if (k % 2 == 1 and self.main_alt is not None) else self.main
-        self.ctx.set_stream(main.cuda_stream)
-        with torch.cuda.stream(main):
-            main.wait_event(self._packed_ev[b])
-            if s.busy and s.psum_free is not None:
-                main.wait_event(s.psum_free)         # the raw sums are the only thing of the slot's previous batch this overwrites
-            if events is not None:
-                events[0].record(main)
-            self.stage_ct(s, buf, mid_event=None if events is None else events[1], finalize=False)
-            self._ct_done_ev[b] = torch.cuda.Event()
-            self._ct_done_ev[b].record(main)
-            s.front_done = self._ct_done_ev[b]
-        s.hist_done = self._packed_ev[b]
-        if pack_next is not None:
-            pack_hist(pack_next, k + 1, events)
-            self._packed = True
         self.ctx.set_stream(self.main.cuda_stream)
         return s
 
@@ -603,8 +515,6 @@ class DevicePipeline:
             self.back(k, None if events is None else events[k])
             if on_enqueued is not None:
                 s.guard = on_enqueued(s)
-                if self.fused and self.aux is not None:
-                    self._hist_guard[k % len(self._hist_pool)] = s.guard
         for k in range(max(0, nb - D), nb):
             s = self.slots[k % D]
             if s.busy:

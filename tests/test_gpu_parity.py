@@ -195,38 +195,46 @@ def test_ct_rfft_traceless_form_and_its_fallback(ctx, liboracle):
     is a float32 unit vector; any other series (scaled vectors, the zero vectors vecnorm_NDarray's 0/0 guard produces)
     takes the sixth transform on |u|^2.  Both must agree with the plain-C float64 oracle at float64 accuracy, also with
     chunk starts that are odd (unaligned 8-byte pairs: the 32-bit load path) and with the series of one launch mixed."""
-    F, R, V = 4096, 3, 6
-    vecs = synth.synth_vectors(R * F + 7, V, seed=77).copy()
-    vecs[:, 1] *= np.float32(1.7)                                   # not unit: whole series scaled
-    vecs[100:140, 2] = 0.0                                          # a few zero vectors (0/0 guard)
-    vecs[:, 3] *= (1.0 + 0.2 * np.sin(np.arange(vecs.shape[0]) / 50.0)).astype(np.float32)[:, None]
-    vecs[F + 5, 4] *= np.float32(1.0 + 2e-6)                        # one frame of one chunk just outside the tolerance
-    v4 = vecs[:R * F].reshape(R, F, V, 3)
-    Cr, dCr = c_oracle_ct(liboracle, v4)
-    Ct, dCt = ctx.ct_palmer(vecs, R, F)
-    assert relerr(Ct, Cr) < 1e-12 and np.max(np.abs(dCt - dCr)) <= 1e-12 * max(1.0, np.max(np.abs(dCr)))
-    # odd chunk starts (two "files" whose first one has an odd number of frames)
-    a = synth.synth_vectors(2 * F + 1, 3, seed=78)
-    b = synth.synth_vectors(F + 9, 3, seed=79)
-    cat = np.ascontiguousarray(np.concatenate([a, b]))               # the odd tail of the first file stays in the array
-    starts = np.array([0, F, 2 * F + 1], dtype=np.int64)
-    v4 = np.stack([cat[st:st + F] for st in starts])
-    Cr, dCr = c_oracle_ct(liboracle, v4)
-    Ct, dCt = ctx.ct_palmer(cat, 3, F, chunk_start=starts)
-    assert relerr(Ct, Cr) < 1e-12 and np.max(np.abs(dCt - dCr)) <= 1e-12
-    # constant unit vectors at the production chunk length: C(t) = 1 to a few ulp, dC(t) = 0
-    const = np.zeros((2 * F, 3, 3), dtype=np.float32)
-    const[:, 0, 0] = 1.0
-    const[:, 1, 1] = 1.0
-    const[:, 2, 2] = -1.0
-    Ct4, dCt4 = ctx.ct_palmer(const, 2, F)
-    assert np.max(np.abs(Ct4 - 1.0)) <= 4e-15 and np.max(np.abs(dCt4)) <= 4e-15
-    # shorter chunks of the same transform length (F = 3000: zero padding inside the loaded blocks)
-    vecs = synth.synth_vectors(2 * 3000, 2, seed=80).copy()
-    vecs[:, 1] *= np.float32(0.5)
-    Cr, dCr = c_oracle_ct(liboracle, vecs.reshape(2, 3000, 2, 3))
-    Ct, dCt = ctx.ct_palmer(vecs, 2, 3000)
-    assert relerr(Ct, Cr) < 1e-12
+    ctx.set_option('ct_traceless', 1)
+    try:
+        F, R, V = 4096, 3, 6
+        vecs = synth.synth_vectors(R * F + 7, V, seed=77).copy()
+        vecs[:, 1] *= np.float32(1.7)                                   # not unit: whole series scaled
+        vecs[100:140, 2] = 0.0                                          # a few zero vectors (0/0 guard)
+        vecs[:, 3] *= (1.0 + 0.2 * np.sin(np.arange(vecs.shape[0]) / 50.0)).astype(np.float32)[:, None]
+        vecs[F + 5, 4] *= np.float32(1.0 + 2e-6)                        # one frame of one chunk just outside the tolerance
+        v4 = vecs[:R * F].reshape(R, F, V, 3)
+        Cr, dCr = c_oracle_ct(liboracle, v4)
+        Ct, dCt = ctx.ct_palmer(vecs, R, F)
+        assert relerr(Ct, Cr) < 1e-12 and np.max(np.abs(dCt - dCr)) <= 1e-12 * max(1.0, np.max(np.abs(dCr)))
+        # odd chunk starts (two "files" whose first one has an odd number of frames)
+        a = synth.synth_vectors(2 * F + 1, 3, seed=78)
+        b = synth.synth_vectors(F + 9, 3, seed=79)
+        cat = np.ascontiguousarray(np.concatenate([a, b]))               # the odd tail of the first file stays in the array
+        starts = np.array([0, F, 2 * F + 1], dtype=np.int64)
+        v4 = np.stack([cat[st:st + F] for st in starts])
+        Cr, dCr = c_oracle_ct(liboracle, v4)
+        Ct, dCt = ctx.ct_palmer(cat, 3, F, chunk_start=starts)
+        assert relerr(Ct, Cr) < 1e-12 and np.max(np.abs(dCt - dCr)) <= 1e-12
+        # constant unit vectors at the production chunk length: C(t) = 1 to a few ulp, dC(t) = 0
+        const = np.zeros((2 * F, 3, 3), dtype=np.float32)
+        const[:, 0, 0] = 1.0
+        const[:, 1, 1] = 1.0
+        const[:, 2, 2] = -1.0
+        Ct4, dCt4 = ctx.ct_palmer(const, 2, F)
+        assert np.max(np.abs(Ct4 - 1.0)) <= 4e-15 and np.max(np.abs(dCt4)) <= 4e-15
+        # shorter chunks of the same transform length (F = 3000: zero padding inside the loaded blocks)
+        vecs = synth.synth_vectors(2 * 3000, 2, seed=80).copy()
+        vecs[:, 1] *= np.float32(0.5)
+        Cr, dCr = c_oracle_ct(liboracle, vecs.reshape(2, 3000, 2, 3))
+        Ct, dCt = ctx.ct_palmer(vecs, 2, 3000)
+        assert relerr(Ct, Cr) < 1e-12
+        # the default (six-signal) kernel on the same input: the two forms agree to the accuracy of either
+        ctx.set_option('ct_traceless', 0)
+        Ct0, dCt0 = ctx.ct_palmer(vecs, 2, 3000)
+        assert relerr(Ct0, Cr) < 1e-12 and relerr(Ct0, Ct) < 1e-12
+    finally:
+        ctx.set_option('ct_traceless', 0)
 
 
 def test_ct_rejects_bad_arguments(ctx):

@@ -52,8 +52,7 @@ def test_pipeline_step_equals_staged_calls(setup, aniso):
         e = hostct.lambert_edges()
         hist, vecsum, outer = ctx.rotate_hist(vecs[: s['N']], np.array(synth.Q_EXT), e[0], e[1], block_len=s['F'])
         assert np.array_equal(sl.hist.cpu().numpy().reshape(hist.shape), hist)
-        # the pipeline's fused pack + histogram kernel adds the float64 sums in another order than k_vechist
-        assert np.max(np.abs(sl.vecsum.cpu().numpy() - vecsum)) <= 1e-12 * np.max(np.abs(vecsum))
+        assert np.array_equal(sl.vecsum.cpu().numpy(), vecsum)
     # kernel 3b: the search on the same C(t)
     t = np.ascontiguousarray(np.broadcast_to(hostct.calculate_dt(s['dt'], s['F'] * s['dt']), (V, s['L'])))
     ref = fitCt.order_search_device(t, np.ascontiguousarray(Ct.T), np.ascontiguousarray(dCt.T), pipe.listDoG, 0.5, ctx=ctx)
@@ -227,10 +226,9 @@ def test_bench_json_contract():
         assert k in r, k
     # every fraction is a fraction of a bound its kernel can reach: in (0, 1]
     ks = j['kernels']
-    assert r['kernel'] in ks and set(ks) >= {'k_ct_rfft', 'k_ct_palmer', 'k_pack_hist', 'k_vechist', 'k_pack_soa', 'k_order_search'}
+    assert r['kernel'] in ks and set(ks) >= {'k_ct_rfft', 'k_ct_palmer', 'k_vechist', 'k_pack_soa', 'k_order_search'}
     top = ks[r['kernel']]
-    in_step = ('k_ct_rfft', 'k_pack_hist', 'k_order_search')          # k_vechist / k_pack_soa / k_ct_palmer are timed alone for comparison
-    assert top['cu_ms_per_batch'] == max(ks[k]['cu_ms_per_batch'] for k in in_step)
+    assert top['cu_ms_per_batch'] == max(v['cu_ms_per_batch'] for k, v in ks.items() if k != 'k_ct_palmer')
     for name, e in ks.items():
         for f in ('frac', 'frac_alone'):
             if e.get(f) is not None:
@@ -241,9 +239,8 @@ def test_bench_json_contract():
     assert 0 < ct['in_pipeline_ms'] < j['ms_per_step'] * 1.05 and ct['alone_ms'] <= ct['in_pipeline_ms'] * 1.05
     assert abs(ct['frac'] - ct['work_per_launch'] / (ct['in_pipeline_ms'] * 1e-3) / 1e12 / ct['peak']) < 1e-9
     assert ct['work_per_launch'] < 0.1 * 8 * j['config']['exact_triples_per_gpu']          # the FFT formulation executes < 10 % of the direct flop
-    vh = ks['k_pack_hist']
+    vh = ks['k_vechist']
     assert vh['bound'] == 'hbm' and abs(vh['achieved'] - vh['work_per_launch'] / (vh['in_pipeline_ms'] * 1e-3) / 1e9) < 1e-6 * vh['achieved']
-    assert 'in_pipeline_ms' not in ks['k_vechist'] and ks['k_vechist']['alone_ms'] > 0
     fit = ks['k_order_search']
     assert fit['residues_per_s'] > 0 and fit['evaluations_per_s'] > fit['residues_per_s'] and fit['saturated_ms_per_batch'] <= fit['alone_ms']
     assert j['latency_ms']['min'] >= j['ms_per_step'] * 0.9          # one batch alone cannot beat the pipelined period by much
@@ -318,80 +315,3 @@ def test_workspace_growth_while_another_stream_is_busy(synth_cache):
         c.stream_destroy(sB)
         c.close()
 
-
-@pytest.mark.parametrize('case', ['blocks_tail_rot', 'chunk_starts_gaps', 'single_block_shard_norot', 'edges_poles_nan'])
-def test_fused_pack_hist_equals_pack_then_hist(setup, case):
-    """sr_pack_hist_f32_dev (kernel 0 + kernel 2 in one pass over the frame-major input) against the two kernels it
-    replaces: the planes bit for bit, the counts exactly, the float64 sums to 1e-12 (other summation order) -- blocks with a
-    tail, ragged vector counts, a vector shard, chunk starts with odd offsets and unused frames between them, no rotation,
-    and samples on bin edges / poles / NaN that must take the exact classification path."""
-    from spinrelax_amd import ct as hostct
-    st = setup
-    torch, ctx, synth, dev = st['torch'], st['ctx'], st['synth'], st['dev']
-    ctx.set_stream(0)
-    e = hostct.lambert_edges()
-    q = np.array(synth.Q_EXT)
-    cs = None
-    if case == 'blocks_tail_rot':
-        frames, Vtot, v0, nV, Fb = 10007, 21, 0, 21, 1024
-        vecs = synth.synth_vectors(frames, Vtot, seed=5)
-        N_hist = 9 * 1024 + 300                         # nine blocks and a tail that only feeds the histogram / mean vector
-    elif case == 'chunk_starts_gaps':
-        frames, Vtot, v0, nV, Fb = 9000, 11, 0, 11, 2001
-        vecs = synth.synth_vectors(frames, Vtot, seed=6)
-        cs = np.array([3, 2004 + 17, 4022 + 2001 + 5], dtype=np.int64)      # odd starts, unused frames in between and behind
-        N_hist = 0
-    elif case == 'single_block_shard_norot':
-        frames, Vtot, v0, nV, Fb = 5000, 40, 13, 19, 0
-        vecs = synth.synth_vectors(frames, Vtot, seed=7)
-        N_hist, q = 4999, None
-    else:
-        frames, Vtot, v0, nV, Fb = 4096, 8, 0, 8, 0
-        vecs = synth.synth_vectors(frames, Vtot, seed=8).copy()
-        rng = np.random.RandomState(3)
-        # exact bin edges in phi and cos(theta), the poles, the seam, zero vectors, NaN
-        k = rng.randint(0, 73, size=frames)
-        c = rng.randint(0, 37, size=frames)
-        ph, ct = e[0][k], np.clip(e[1][c], -1, 1)
-        st_ = np.sqrt(1 - ct * ct)
-        vecs[:, 0] = np.stack((st_ * np.cos(ph), st_ * np.sin(ph), ct), -1).astype(np.float32)
-        vecs[::7, 1] = (0, 0, 1)
-        vecs[1::7, 1] = (0, 0, -1)
-        vecs[2::7, 1] = (-1, 0, 0)
-        vecs[3::7, 1] = (-1, -0.0, 0)
-        vecs[5::11, 2] = 0.0
-        vecs[7::13, 3] = np.nan
-        N_hist, q = frames, None
-    Npad = (frames + 63) // 64 * 64
-    dv = torch.from_numpy(vecs).to(dev)
-    nb = 72 * 36
-    nB = len(cs) if cs is not None else (N_hist // Fb if Fb else 1)
-
-    def bufs():
-        return (torch.zeros((nV, 3, Npad), device=dev, dtype=torch.float32), torch.empty((nV, nb), device=dev, dtype=torch.float64),
-                torch.empty((nV, 3), device=dev, dtype=torch.float64), torch.empty((nB, nV, 6), device=dev, dtype=torch.float64))
-    soa1, h1, s1, o1 = bufs()
-    assert ctx.pack_hist_dev(dv.data_ptr(), frames, Vtot, v0, nV, soa1.data_ptr(), Npad, N_hist, q, e[0], e[1], h1.data_ptr(),
-                             s1.data_ptr(), o1.data_ptr(), Fb, chunk_start=cs)
-    soa2, h2, s2, o2 = bufs()
-    ctx.pack_soa_dev(dv.data_ptr(), frames, Vtot, v0, nV, soa2.data_ptr(), Npad)
-    if cs is None:
-        ctx.rotate_hist_dev(soa2.data_ptr(), Npad, N_hist, nV, q, e[0], e[1], h2.data_ptr(), s2.data_ptr(), o2.data_ptr(), Fb)
-        ctx.sync()
-        torch.cuda.synchronize()
-        hist2, sum2, out2 = h2.cpu().numpy(), s2.cpu().numpy(), o2.cpu().numpy()
-    else:
-        # reference for the chunked case: the used frames gathered on the host, as the reference's reformat_vecs_by_tau does
-        used = np.ascontiguousarray(np.concatenate([vecs[c0:c0 + Fb] for c0 in cs]))
-        hist2, sum2, out2 = ctx.rotate_hist(used, q, e[0], e[1], v0=v0, nV=nV, block_len=Fb)
-        hist2 = hist2.reshape(nV, nb)
-    ctx.sync()
-    torch.cuda.synchronize()
-    assert torch.equal(soa1.view(torch.int32), soa2.view(torch.int32))          # bit for bit, NaN included
-    assert np.array_equal(h1.cpu().numpy(), hist2)
-    if case == 'edges_poles_nan':
-        assert hist2.sum() < frames * nV                         # zero vectors and NaN are dropped, like numpy does
-    for got, want in ((s1.cpu().numpy(), sum2), (o1.cpu().numpy(), out2)):
-        ok = np.isfinite(want)
-        assert np.array_equal(np.isfinite(got), ok)
-        assert np.max(np.abs(got[ok] - want[ok])) <= 1e-12 * max(1.0, np.max(np.abs(want[ok])))

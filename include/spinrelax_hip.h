@@ -21,6 +21,8 @@
  *     ordered before the next, e.g. same stream).  sr_expfit_order_search_f64_dev (with its `work` argument),
  *     sr_expfit_lm_f64_dev (ditto), sr_jomega_relax_f64_dev and sr_transpose_f64_dev use caller memory only and
  *     may run on several streams at once -- that is how spinrelax_amd/pipeline.py overlaps batches;
+ *   - small HOST tables handed to "_dev" entry points (atom index lists, lag lists, chunk starts, a quaternion, bin edges)
+ *     are validated before anything is queued and are consumed when the call returns: the caller may free them at once;
  *   - there is no CPU fallback: without a gfx950 device sr_create fails.
  */
 #ifndef SPINRELAX_HIP_H
@@ -35,7 +37,7 @@ extern "C" {
 
 typedef struct sr_ctx sr_ctx;
 
-#define SR_ABI_VERSION 2
+#define SR_ABI_VERSION 3
 
 /* ---- context, memory, timing ------------------------------------------------------------- */
 int          sr_abi_version(void);
@@ -154,6 +156,44 @@ int sr_rotate_vectors_f32(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, 
 /* one quaternion per frame: quat (N, 4) float64 host array, already normalised; out (N, nV, 3) float64. */
 int sr_rotate_vectors_perframe_f32(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,
                                    const double *quat, double *out);
+
+/* ---- resident bond vectors: upload once, pack once (a rank owns a vector range) --------------
+ * The reference keeps vecXH / vecXHfit in host arrays (calculate-Ct-from-traj.py:464-498) and reads them for C(t) of the
+ * lab-frame vectors (:527), C(t) of the fitted ones (:530) and the rotation + histogram + mean vector + S2 pass (:541-646).
+ * An sr_vectors object holds ONE rank's columns [v0, v0 + nV) of such an array on the device:
+ *   sr_vectors_create        nV vectors, room for capacity_frames frames (grows when more are appended); NULL on failure
+ *   sr_vectors_append_f32    n more frames from a HOST array (n, Vtot, 3): only the bytes of columns [v0, v0 + nV) cross
+ *                            PCIe (row pitch 12 Vtot, width 12 nV), through two pinned staging buffers; synchronous with
+ *                            respect to the host array, asynchronous on the device
+ *   sr_vectors_append_dev    n more frames from a DEVICE array (n, nV, 3) (e.g. an output of sr_xh_vectors_f32_dev)
+ *   sr_vectors_append_xyz_f32  n more frames straight from HOST coordinates: obtain_XHvecs (+ centre / superpose) of
+ *                            sr_xh_vectors_f32_dev for the bonds idxX[i] -> idxH[i], i < nV (the rank's slice of the
+ *                            selections), written into `lab` and / or `fit` (either may be NULL) -- the streaming form of
+ *                            the reference's --split loop (:426-453): the host never holds more than one chunk
+ *   sr_vectors_truncate      keep the first n_frames frames (reformat_vecs_by_tau drops the tail of every file that does not fill
+ *                            a block of memory time, calculate-Ct-from-traj.py:259-272: a streamed file is cut when it ends)
+ *   sr_vectors_download_f32  frames [f0, f0 + n) back to the host as (n, nV, 3) (the --vecDist outputs need them)
+ *   sr_vectors_ct_f32        kernel 0 (once per object) + kernel 1: as sr_ct_palmer_f32, Ct / dCt (F/2, nV) on the host
+ *   sr_vectors_hist_f32      kernel 0 (once per object) + kernel 2 over the first N_hist frames (<= 0: all): as
+ *                            sr_rotate_hist_f32
+ * sr_counter(ctx, "h2d_vector_bytes" | "vector_uploads"): bytes and calls of sr_vectors_append_f32 since sr_create (the
+ * host-pointer entry points sr_ct_palmer_f32 / sr_rotate_hist_f32 go through it too). */
+typedef struct sr_vectors sr_vectors;
+sr_vectors *sr_vectors_create(sr_ctx *, int64_t nV, int64_t capacity_frames);
+void        sr_vectors_destroy(sr_ctx *, sr_vectors *);
+int64_t     sr_vectors_frames(const sr_vectors *);
+int sr_vectors_truncate(sr_ctx *, sr_vectors *, int64_t n_frames);
+int sr_vectors_append_f32(sr_ctx *, sr_vectors *, const float *vecs_host, int64_t n, int64_t Vtot, int64_t v0);
+int sr_vectors_append_dev(sr_ctx *, sr_vectors *, const float *vecs_dev, int64_t n);
+int sr_vectors_append_xyz_f32(sr_ctx *, sr_vectors *lab, sr_vectors *fit, const float *xyz_host, int64_t nFrames, int64_t nAtoms,
+                              const int32_t *idxX, const int32_t *idxH, int nV, const int32_t *fit_idx, int nFit,
+                              const float *ref_xyz);
+int sr_vectors_download_f32(sr_ctx *, const sr_vectors *, int64_t f0, int64_t n, float *out_host);
+int sr_vectors_ct_f32(sr_ctx *, sr_vectors *, int64_t R, int64_t F, const int64_t *chunk_start_host, int mode,
+                      double *Ct, double *dCt);
+int sr_vectors_hist_f32(sr_ctx *, sr_vectors *, int64_t N_hist, const double *q, const double *edges_phi, int nphi,
+                        const double *edges_cos, int ncos, double *hist, double *vecsum, double *outer, int64_t block_len);
+int sr_counter(sr_ctx *, const char *name, uint64_t *value);
 
 /* ---- kernel 3b: multi-exponential C(t) model --------------------------------------------
  * Model of curvefit_exponential (fitting_Ct_functions.py:419-427): params = [C_1..C_K, tau_1..tau_K

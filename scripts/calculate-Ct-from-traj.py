@@ -101,13 +101,20 @@ def load_vector_files(files, default_dt):
     return resXH, lab, body, dt
 
 
-def load_mdtraj(args):
-    """The reference's loader (calculate-Ct-from-traj.py:396-498) on top of MDTraj."""
+def load_mdtraj(args, frames_per_chunk_of):
+    """The reference's loader (calculate-Ct-from-traj.py:396-498) on top of MDTraj, STREAMING: MDTraj reads the file (in
+    chunks of --split frames, `md.iterload`, like the reference's :426-453, or 1000 frames otherwise) and resolves the
+    selections; every chunk's coordinates go to the GPU, where the bond vectors, the centring and the per-frame superposition
+    are computed and APPENDED to this rank's resident vectors (spinrelax_amd.hip.ResidentVectors) -- the host never holds
+    more than one chunk of coordinates and no vectors at all.  A file's tail that does not fill a block of memory time is
+    cut when the file ends (reformat_vecs_by_tau, :259-272).  frames_per_chunk_of(dt) -> frames per block or None.
+    Returns (resXH, lab vectors, fitted vectors, deltaT, total vectors V, first vector i0, frames kept)."""
     try:
         import mdtraj as md
     except ImportError:
         print("= = = ERROR: MDTraj is not installed; give precomputed vectors as .npy/.npz to -f instead.", file=sys.stderr)
         sys.exit(1)
+    from spinrelax_amd import hip
 
     def select(traj):
         iX = traj.topology.select(args.Xseltxt)
@@ -126,26 +133,38 @@ def load_mdtraj(args):
             return [inds[i] for i in range(len(mask)) if mask[i] > 0.0]
         return ref.topology.select(args.fittxt)
 
-    resXH, lab, body, dt = None, [], [], None
+    ctx = hip.default_context()
+    resXH, dt, lab, fit, V, i0, nloc = None, None, None, None, None, 0, 0
     for i, fn in enumerate(args.infn):
         top = args.topfn[i] if len(args.topfn) > 1 else args.topfn[0]
         ref = md.load(top)
         fi = fit_indices(ref, top)
-        chunks = md.iterload(fn, chunk=1000, top=top) if args.nSplitFrames > 0 else [md.load(fn, top=top)]
-        l, b = [], []
-        for trj in chunks:
+        nchunk = args.nSplitFrames if args.nSplitFrames > 0 else 1000
+        file_start = 0 if lab is None else lab.frames
+        nfile = 0
+        for trj in md.iterload(fn, chunk=nchunk, top=top):
             names = [trj.topology.atom(k).residue.resSeq for k in trj.topology.select(args.Hseltxt)]
             d = trj.timestep
-            # MDTraj reads the file and resolves the selections; vectors, centring and superposition run on the GPU
             iX, iH = select(trj)
-            vl, vb = hostct.superpose_XHvecs(trj.xyz, ref.xyz[0], fi, iX, iH)
-            l.append(vl)
-            b.append(vb)
-        if resXH is None:
-            resXH, dt = names, d
-        lab.append(np.concatenate(l, axis=0))
-        body.append(np.concatenate(b, axis=0))
-    return resXH, lab, body, dt
+            if resXH is None:
+                resXH, dt, V = names, d, len(iX)
+                i0, nloc = srdist.my_range(V) if srdist.world() > 1 else (0, V)
+                if nloc > 0:
+                    lab, fit = ctx.vectors(nloc), ctx.vectors(nloc)
+            elif dt != d or resXH != names:
+                print("= = = ERROR: Differences in trajectories have been detected! Aborting.", file=sys.stderr)
+                sys.exit(1)
+            if nloc > 0:
+                hip.append_xyz(ctx, lab, fit, trj.xyz, iX[i0:i0 + nloc], iH[i0:i0 + nloc], fi, ref.xyz[0])
+            nfile += trj.xyz.shape[0]
+        F = frames_per_chunk_of(dt)
+        keep = nfile if F is None else (nfile // F) * F
+        if nloc > 0 and keep != nfile:
+            lab.truncate(file_start + keep)
+            fit.truncate(file_start + keep)
+        print("= = = Molecule centered and fitted: %s, %i frames read, %i kept." % (fn, nfile, keep))
+    frames = 0 if lab is None else lab.frames
+    return resXH, lab, fit, dt, V, i0, frames
 
 
 def main():
@@ -170,38 +189,54 @@ def main():
         print("= = ERROR: When giving multiple reference files, you must have one for each trajecfile file given!", file=sys.stderr)
         sys.exit(1)
 
+    def frames_per_chunk_of(dt):
+        if tau_memory is None:
+            return None
+        if dt > 0.5 * tau_memory:
+            print("= = = ERROR: delta-t form the trajectory is too small relative to tau! %g vs. %g" % (dt, tau_memory), file=sys.stderr)
+            sys.exit(1)
+        return int(tau_memory / dt)
+
+    host_fit = None          # host copy of the fitted vectors (vector-file input only; the --vecDist listing needs it)
     if all(f.endswith('.npy') or f.endswith('.npz') for f in args.infn):
         resXH, vecXH, vecXHfit, deltaT = load_vector_files(args.infn, args.dt)
-    else:
-        resXH, vecXH, vecXHfit, deltaT = load_mdtraj(args)
-    if args.qfile is not None:
-        from spinrelax_amd import plumedcolvario
-        if len(args.qfile) != len(vecXH):
-            print("= = = ERROR: --qfile needs one orientation file per trajectory file!", file=sys.stderr)
-            sys.exit(1)
-        print("= = = De-tumbling the lab-frame vectors with the per-frame orientation quaternions.")
-        vecXHfit = []
-        for fn, lab in zip(args.qfile, vecXH):
-            _, q = plumedcolvario.read_qorient(fn)
-            if q.shape[0] != lab.shape[0]:
-                print("= = = ERROR: %s holds %i frames, the trajectory %i!" % (fn, q.shape[0], lab.shape[0]), file=sys.stderr)
+        if args.qfile is not None:
+            from spinrelax_amd import plumedcolvario
+            if len(args.qfile) != len(vecXH):
+                print("= = = ERROR: --qfile needs one orientation file per trajectory file!", file=sys.stderr)
                 sys.exit(1)
-            vecXHfit.append(hostct.detumble_vectors(lab, q))
-    if tau_memory is not None and deltaT > 0.5 * tau_memory:
-        print("= = = ERROR: delta-t form the trajectory is too small relative to tau! %g vs. %g" % (deltaT, tau_memory), file=sys.stderr)
-        sys.exit(1)
+            print("= = = De-tumbling the lab-frame vectors with the per-frame orientation quaternions.")
+            vecXHfit = []
+            for fn, lab in zip(args.qfile, vecXH):
+                _, q = plumedcolvario.read_qorient(fn)
+                if q.shape[0] != lab.shape[0]:
+                    print("= = = ERROR: %s holds %i frames, the trajectory %i!" % (fn, q.shape[0], lab.shape[0]), file=sys.stderr)
+                    sys.exit(1)
+                vecXHfit.append(hostct.detumble_vectors(lab, q))
+        F = frames_per_chunk_of(deltaT)
+        # ONE upload per vector set, of this rank's columns only; when the file holds no separate lab-frame vectors the two
+        # sets are the same arrays and share the resident copy
+        same = all(a is b for a, b in zip(vecXH, vecXHfit)) and len(vecXH) == len(vecXHfit)
+        rv_fit, V, i0, N = hostct.upload_shard(vecXHfit, F)
+        rv_lab = rv_fit if same or not args.bDoCt else hostct.upload_shard(vecXH, F)[0]
+        host_fit = vecXHfit
+        del vecXH
+    else:
+        if args.qfile is not None:
+            print("= = = ERROR: --qfile works on vector-file input (.npy/.npz), not on MDTraj input.", file=sys.stderr)
+            sys.exit(1)
+        resXH, rv_lab, rv_fit, deltaT, V, i0, N = load_mdtraj(args, frames_per_chunk_of)
+        F = frames_per_chunk_of(deltaT)
+        if N < 1:
+            print("= = = ERROR: no trajectory holds a full block of memory time tau!", file=sys.stderr)
+            sys.exit(1)
     print("= = Loading finished.")
     out_pref = srdist.output_prefix(args.out_pref)
 
     if tau_memory is not None:
-        F = int(tau_memory / deltaT)
         print("= = Reformatting all vecXH information into chunks of tau ( %g ) " % tau_memory)
         print("    ...debug: Using %i frames per chunk based on tau/dt (%g/%g)." % (F, tau_memory, deltaT))
-        used = [v[: (v.shape[0] // F) * F] for v in vecXHfit]          # reformat_vecs_by_tau drops each file's tail
-        vec3d = used[0] if len(used) == 1 else np.concatenate(used, axis=0)
-    else:
-        F = None
-        vec3d = vecXHfit[0] if len(vecXHfit) == 1 else np.concatenate(vecXHfit, axis=0)
+        R = N // F
 
     if args.bDoCt:
         mode = 1 if args.exact else 0
@@ -209,20 +244,32 @@ def main():
         print("= = = Conducting Ct_external using Palmer's approach.")
         print("= = = timestep: ", deltaT, "ps")
         print("= = = tau_memory: ", tau_memory, "ps")
-        Ct, dCt = hostct.calculate_Ct_from_files(vecXH, deltaT, tau_memory, mode=mode)
+        Ct, dCt = hostct.calculate_Ct_resident(rv_lab, V, R, F, mode=mode)
         gs.print_sxylist(out_pref + '_Ctext.dat', resXH, dt, np.stack((Ct.T, dCt.T), axis=-1))
         print("= = = Conducting Ct_internal using Palmer's approach.")
-        Ct, dCt = hostct.calculate_Ct_from_files(vecXHfit, deltaT, tau_memory, mode=mode)
+        if rv_fit is not rv_lab:
+            Ct, dCt = hostct.calculate_Ct_resident(rv_fit, V, R, F, mode=mode)
         gs.print_sxylist(out_pref + '_Ctint.dat', resXH, dt, np.stack((Ct.T, dCt.T), axis=-1))
-    del vecXH
+    if rv_lab is not None and rv_lab is not rv_fit:
+        rv_lab.close()
 
     need_dist = args.bDoVecAverage or args.bDoS2 or (bDoVecDistrib and args.bDoVecHist)
     if need_dist:
         if q_rot is not None:
             print("= = = Rotating all fitted vectors by the input quaternion into PAF.")
-        dist = hostct.vector_distribution(vec3d, q_rot, histBinX=args.histBin,
-                                          delta_t=deltaT if tau_memory is not None else -1,
-                                          tau_memory=tau_memory if tau_memory is not None else -1)
+        dist = hostct.vector_distribution_resident(rv_fit, V, N, q_rot, histBinX=args.histBin,
+                                                   delta_t=deltaT if tau_memory is not None else -1,
+                                                   tau_memory=tau_memory if tau_memory is not None else -1)
+    if bDoVecDistrib and not args.bDoVecHist:
+        # the full (phi, theta) listing needs every rotated vector on the host
+        if host_fit is not None:
+            used = [v[: (v.shape[0] // F) * F] if tau_memory is not None else v for v in host_fit]
+            vec3d = used[0] if len(used) == 1 else np.concatenate(used, axis=0)
+        else:
+            part = rv_fit.download() if rv_fit is not None else np.empty((N, 0, 3), dtype=np.float32)
+            vec3d = srdist.gather_rows(part, V, axis=1) if srdist.world() > 1 else part
+    if rv_fit is not None:
+        rv_fit.close()
     if args.bDoVecAverage:
         gs.print_xylist(out_pref + '_avgvec.dat', resXH, np.array(dist['avgvec']).T, True)
     if bDoVecDistrib:

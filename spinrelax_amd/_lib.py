@@ -87,6 +87,19 @@ SIGNATURES = {
     'sr_rscsa_search_f64': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p, c_double, c_double, c_double, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
+    'sr_vectors_create': (c_void_p, [c_void_p, c_int64, c_int64]),
+    'sr_vectors_destroy': (None, [c_void_p, c_void_p]),
+    'sr_vectors_frames': (c_int64, [c_void_p]),
+    'sr_vectors_truncate': (c_int, [c_void_p, c_void_p, c_int64]),
+    'sr_vectors_append_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64]),
+    'sr_vectors_append_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
+    'sr_vectors_append_xyz_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int,
+                                          c_void_p, c_int, c_void_p]),
+    'sr_vectors_download_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'sr_vectors_ct_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
+    'sr_vectors_hist_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_int64]),
+    'sr_counter': (c_int, [c_void_p, c_char_p, POINTER(ctypes.c_uint64)]),
     'sr_transpose_f64_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'sr_jomega_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     'sr_jomega_relax_f64': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -95,7 +108,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 2
+ABI_VERSION = 3
 LIB_PATH = os.environ.get('SPINRELAX_HIP_LIB', LIB_PATH)      # alternative build of the same ABI
 
 

@@ -91,6 +91,11 @@ void sr_destroy(sr_ctx *ctx)
         if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->stage[i]) {
+            (void)hipHostFree(ctx->stage[i]);
+            (void)hipEventDestroy(ctx->stage_ev[i]);
+        }
     delete ctx;
 }
 

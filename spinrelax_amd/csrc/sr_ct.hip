@@ -1455,6 +1455,7 @@ int sr_ct_palmer_sums_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64
         cs_dev = (int64_t *)sr_workspace(ctx, SR_WS_MISC, (size_t)R * sizeof(int64_t));
         if (!cs_dev) return -5;
         SR_HIP(hipMemcpyAsync(cs_dev, chunk_start_host, (size_t)R * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        SR_HIP(hipStreamSynchronize(ctx->stream));      // tiny table: the caller's array is free again when this returns
     }
     CtArgs a;
     a.soa = soa; a.Npad = Npad; a.chunk_start = cs_dev; a.psum = psum;
@@ -1545,23 +1546,13 @@ int sr_ct_palmer_f32(sr_ctx *ctx, const float *vecs, int64_t N, int64_t Vtot, in
     SR_CHECK_CTX(ctx);
     SR_REQUIRE(vecs && Ct && dCt, -2, "sr_ct_palmer_f32: null pointer");
     SR_REQUIRE(N > 0 && Vtot > 0 && nV > 0 && v0 >= 0 && v0 + nV <= Vtot, -3, "sr_ct_palmer_f32: bad shape");
-    const int64_t Npad = sr_round_up(N, 64);
-    const size_t in_bytes = (size_t)N * Vtot * 3 * sizeof(float);
-    float *dvecs = (float *)sr_workspace(ctx, SR_WS_VECS, in_bytes);
-    float *soa = (float *)sr_workspace(ctx, SR_WS_SOA, (size_t)nV * 3 * Npad * sizeof(float));
-    const int64_t L = F / 2;
-    double *dCt_d = (double *)sr_workspace(ctx, SR_WS_OUT1, (size_t)(L * nV) * sizeof(double));
-    double *Ct_d = (double *)sr_workspace(ctx, SR_WS_OUT0, (size_t)(L * nV) * sizeof(double));
-    if (!dvecs || !soa || !Ct_d || !dCt_d) return -5;
-    SR_HIP(hipMemcpyAsync(dvecs, vecs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-    int rc = sr_pack_soa_f32_dev(ctx, dvecs, N, Vtot, v0, nV, soa, Npad);
-    if (rc) return rc;
-    rc = sr_ct_palmer_f32_dev(ctx, soa, Npad, R, F, nV, chunk_start_host, mode, nullptr, Ct_d, dCt_d);
-    if (rc) return rc;
-    SR_HIP(hipMemcpyAsync(Ct, Ct_d, (size_t)(L * nV) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SR_HIP(hipMemcpyAsync(dCt, dCt_d, (size_t)(L * nV) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SR_HIP(hipStreamSynchronize(ctx->stream));
-    return 0;
+    // the rank's columns [v0, v0 + nV) only: 12 N nV bytes over PCIe (sr_vectors.hip), then kernel 0 and kernel 1
+    sr_vectors *h = sr_vectors_create(ctx, nV, N);
+    if (!h) return -5;
+    int rc = sr_vectors_append_f32(ctx, h, vecs, N, Vtot, v0);
+    if (!rc) rc = sr_vectors_ct_f32(ctx, h, R, F, chunk_start_host, mode, Ct, dCt);
+    sr_vectors_destroy(ctx, h);
+    return rc;
 }
 
 }  // extern "C"

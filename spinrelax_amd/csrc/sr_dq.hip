@@ -134,7 +134,9 @@ int sr_dq_moments_f32_dev(sr_ctx *ctx, const float *q, int64_t N, const int32_t 
     int *lags_d = (int *)sr_workspace(ctx, SR_WS_IN3, (size_t)nlags * sizeof(int));
     double *partials = (double *)sr_workspace(ctx, SR_WS_OUT3, (size_t)nlags * nchunk * nsub * 6 * sizeof(double));
     if (!lags_d || !partials) return -5;
+    // the lag table is tiny: its copy is complete when this function returns (the caller may free it, pinned or not)
     SR_HIP(hipMemcpyAsync(lags_d, lags_host, (size_t)nlags * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    SR_HIP(hipStreamSynchronize(ctx->stream));
     DqArgs a;
     a.q = reinterpret_cast<const float4 *>(q); a.N = N; a.lags = lags_d; a.nlags = nlags; a.nchunk = nchunk;
     a.nsub = (int)nsub; a.partials = partials;

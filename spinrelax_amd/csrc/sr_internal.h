@@ -27,6 +27,11 @@ struct sr_ctx {
     // largest dynamic-LDS size already granted per kernel family (hipFuncSetAttribute is a per-DEVICE setting and a
     // context is bound to one device, so the cache lives here and not in a process-wide static)
     size_t lds_granted[8];
+    // strided host -> device copies of bond vectors (sr_vectors.hip): two pinned staging buffers, and what went through them
+    void *stage[2];
+    hipEvent_t stage_ev[2];
+    int stage_busy[2];
+    unsigned long long h2d_bytes, h2d_calls;
 };
 
 enum { SR_K_CT1 = 0, SR_K_CT4, SR_K_VECHIST, SR_K_DQ, SR_K_MISC };

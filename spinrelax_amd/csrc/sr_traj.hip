@@ -190,31 +190,33 @@ int sr_xh_vectors_f32_dev(sr_ctx *ctx, const float *xyz, int64_t nFrames, int64_
     for (int v = 0; v < nV; ++v)
         SR_REQUIRE(idxX_host[v] >= 0 && idxX_host[v] < nAtoms && idxH_host[v] >= 0 && idxH_host[v] < nAtoms, -3,
                    "sr_xh_vectors_f32_dev: bond %d atom index out of range", v);
+    // every host table is checked BEFORE anything is queued, and the (small) table copies are complete when this function
+    // returns: the caller may free or reuse idxX / idxH / fit_idx / ref_xyz right away, pinned or not
+    if (fit)
+        for (int i = 0; i < nFit; ++i)
+            SR_REQUIRE(fit_idx_host[i] >= 0 && fit_idx_host[i] < nAtoms, -3, "sr_xh_vectors_f32_dev: fit atom %d out of range", i);
     const size_t ibytes = (size_t)(2 * nV + (fit ? nFit : 0)) * sizeof(int);
     int *idx_d = (int *)sr_workspace(ctx, SR_WS_IN2, ibytes);
     double *refc_d = fit ? (double *)sr_workspace(ctx, SR_WS_IN1, (size_t)nFit * 3 * sizeof(double)) : nullptr;
     if (!idx_d || (fit && !refc_d)) return -5;
-    // staging buffers of the host-side tables (pageable memory: the copies are synchronous with respect to the host)
-    SR_HIP(hipMemcpyAsync(idx_d, idxX_host, (size_t)nV * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    SR_HIP(hipMemcpyAsync(idx_d + nV, idxH_host, (size_t)nV * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    if (fit) {
+    double *tmp = nullptr;
+    hipError_t e = hipMemcpyAsync(idx_d, idxX_host, (size_t)nV * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(idx_d + nV, idxH_host, (size_t)nV * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+    if (fit && e == hipSuccess) {
         double c[3] = {0, 0, 0};
-        for (int i = 0; i < nFit; ++i) {
-            SR_REQUIRE(fit_idx_host[i] >= 0 && fit_idx_host[i] < nAtoms, -3, "sr_xh_vectors_f32_dev: fit atom %d out of range", i);
+        for (int i = 0; i < nFit; ++i)
             for (int k = 0; k < 3; ++k) c[k] += (double)ref_xyz_host[(size_t)fit_idx_host[i] * 3 + k];
-        }
         for (int k = 0; k < 3; ++k) c[k] /= (double)nFit;
-        double *tmp = new double[(size_t)nFit * 3];
+        tmp = new double[(size_t)nFit * 3];
         for (int i = 0; i < nFit; ++i)
             for (int k = 0; k < 3; ++k) tmp[(size_t)i * 3 + k] = (double)ref_xyz_host[(size_t)fit_idx_host[i] * 3 + k] - c[k];
-        // in stream order behind whatever still reads the work area; the temporary must outlive the copy
-        hipError_t e1 = hipMemcpyAsync(refc_d, tmp, (size_t)nFit * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-        hipError_t e2 = hipStreamSynchronize(ctx->stream);
-        delete[] tmp;
-        SR_HIP(e1);
-        SR_HIP(e2);
-        SR_HIP(hipMemcpyAsync(idx_d + 2 * nV, fit_idx_host, (size_t)nFit * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        e = hipMemcpyAsync(refc_d, tmp, (size_t)nFit * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(idx_d + 2 * nV, fit_idx_host, (size_t)nFit * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
     }
+    const hipError_t es = hipStreamSynchronize(ctx->stream);
+    delete[] tmp;
+    SR_HIP(e);
+    SR_HIP(es);
     XhArgs a;
     a.xyz = xyz; a.nFrames = nFrames; a.nAtoms = nAtoms; a.idxX = idx_d; a.idxH = idx_d + nV; a.nV = nV;
     a.fit = fit ? idx_d + 2 * nV : nullptr; a.refc = refc_d; a.nFit = fit ? nFit : 0;

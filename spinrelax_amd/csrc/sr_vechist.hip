@@ -500,27 +500,12 @@ int sr_rotate_hist_f32(sr_ctx *ctx, const float *vecs, int64_t N, int64_t Vtot, 
     SR_CHECK_CTX(ctx);
     SR_REQUIRE(vecs && hist, -2, "sr_rotate_hist_f32: null pointer");
     SR_REQUIRE(N > 0 && Vtot > 0 && nV > 0 && v0 >= 0 && v0 + nV <= Vtot, -3, "sr_rotate_hist_f32: bad shape");
-    const int64_t Npad = sr_round_up(N, 64);
-    const size_t in_bytes = (size_t)N * Vtot * 3 * sizeof(float);
-    const int nbins = nphi * ncos;
-    const int64_t Fb = (block_len > 0 && block_len <= N) ? block_len : N;
-    const int64_t nB = N / Fb;
-    float *dvecs = (float *)sr_workspace(ctx, SR_WS_VECS, in_bytes);
-    float *soa = (float *)sr_workspace(ctx, SR_WS_SOA, (size_t)nV * 3 * Npad * sizeof(float));
-    double *hist_d = (double *)sr_workspace(ctx, SR_WS_OUT0, (size_t)nV * nbins * sizeof(double));
-    double *vs_d = (double *)sr_workspace(ctx, SR_WS_OUT1, (size_t)nV * 3 * sizeof(double));
-    double *outer_d = (double *)sr_workspace(ctx, SR_WS_IN0, (size_t)nB * nV * 6 * sizeof(double));
-    if (!dvecs || !soa || !hist_d || !vs_d || !outer_d) return -5;
-    SR_HIP(hipMemcpyAsync(dvecs, vecs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-    int rc = sr_pack_soa_f32_dev(ctx, dvecs, N, Vtot, v0, nV, soa, Npad);
-    if (rc) return rc;
-    rc = sr_rotate_hist_f32_dev(ctx, soa, Npad, N, nV, q, edges_phi, nphi, edges_cos, ncos, hist_d, vs_d, outer_d, block_len);
-    if (rc) return rc;
-    SR_HIP(hipMemcpyAsync(hist, hist_d, (size_t)nV * nbins * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (vecsum) SR_HIP(hipMemcpyAsync(vecsum, vs_d, (size_t)nV * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (outer) SR_HIP(hipMemcpyAsync(outer, outer_d, (size_t)nB * nV * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SR_HIP(hipStreamSynchronize(ctx->stream));
-    return 0;
+    sr_vectors *h = sr_vectors_create(ctx, nV, N);            // the rank's columns only (sr_vectors.hip)
+    if (!h) return -5;
+    int rc = sr_vectors_append_f32(ctx, h, vecs, N, Vtot, v0);
+    if (!rc) rc = sr_vectors_hist_f32(ctx, h, N, q, edges_phi, nphi, edges_cos, ncos, hist, vecsum, outer, block_len);
+    sr_vectors_destroy(ctx, h);
+    return rc;
 }
 
 int sr_rotate_vectors_f32(sr_ctx *ctx, const float *vecs, int64_t N, int64_t Vtot, int64_t v0, int64_t nV,

@@ -94,6 +94,62 @@ def calculate_Ct_from_files(vec_list, dt, tau, ctx=None, mode=0, v0=0, nV=None):
     return _ctx(ctx).ct_palmer(cat, R, F, v0=v0, nV=nV, chunk_start=starts, mode=mode)
 
 
+def upload_shard(vec_list, frames_per_chunk=None, ctx=None):
+    """The product path's single upload: this rank's vector range (srdist.my_range; everything in a single process) of the
+    files' vectors, each file cut to whole chunks of frames_per_chunk frames when given (reformat_vecs_by_tau,
+    calculate-Ct-from-traj.py:245-275), appended one after the other to a hip.ResidentVectors object.  Only the rank's
+    columns cross PCIe, once; C(t) and the vector distribution then read the same planes.
+    Returns (resident vectors, total vectors V, first vector i0, frames held)."""
+    c = _ctx(ctx)
+    V = vec_list[0].shape[1]
+    i0, nloc = srdist.my_range(V) if srdist.world() > 1 else (0, V)
+    used = []
+    for v in vec_list:
+        n = v.shape[0] if frames_per_chunk is None else (v.shape[0] // frames_per_chunk) * frames_per_chunk
+        if n > 0:
+            used.append((v, n))
+    if not used:
+        print("= = = ERROR: no trajectory holds a full block of memory time tau!", file=sys.stderr)
+        sys.exit(1)
+    N = sum(n for _, n in used)
+    if nloc == 0:
+        return None, V, i0, N
+    rv = c.vectors(nloc, N)
+    for v, n in used:
+        rv.append(v[:n], v0=i0)
+    return rv, V, i0, N
+
+
+def calculate_Ct_resident(rv, V, R, F, mode=0):
+    """calculate_Ct_Palmer of resident vectors (regular chunks r*F: the unused tails were dropped at upload); all ranks
+    receive the whole (lags, V) arrays."""
+    L = F // 2
+    if rv is not None:
+        Ct, dCt = rv.ct(R, F, mode=mode)
+    else:
+        Ct, dCt = np.empty((L, 0)), np.empty((L, 0))
+    if srdist.world() > 1:
+        return srdist.gather_rows(Ct, V, axis=1), srdist.gather_rows(dCt, V, axis=1)
+    return Ct, dCt
+
+
+def vector_distribution_resident(rv, V, N, q_rot=None, histBinX=72, delta_t=-1, tau_memory=-1):
+    """vector_distribution() on resident vectors: same result dictionary."""
+    edges = lambert_edges(histBinX)
+    Fb = 0 if (delta_t < 0 or tau_memory < 0) else int(tau_memory / delta_t)
+    if rv is not None:
+        hist, vecsum, outer = rv.hist(q_rot, edges[0], edges[1], block_len=Fb, N_hist=N)
+    else:
+        nB = N // Fb if Fb else 1
+        hist, vecsum, outer = np.empty((0, histBinX, int(histBinX / 2))), np.empty((0, 3)), np.empty((nB, 0, 6))
+    if srdist.world() > 1:
+        hist, vecsum = srdist.gather_rows(hist, V, axis=0), srdist.gather_rows(vecsum, V, axis=0)
+        outer = srdist.gather_rows(outer, V, axis=1)
+    mean = vecsum / N
+    avgvec = mean / np.sqrt((mean ** 2).sum(-1))[..., np.newaxis]
+    return dict(hist=hist, edges=edges, avgvec=avgvec, S2=S2_from_outer_sums(outer, Fb if Fb else N, blocked=bool(Fb)))
+
+
 def lambert_edges(histBinX=72):
     """The bin edges numpy.histogramdd builds at calculate-Ct-from-traj.py:618 for
     bins=(histBinX, int(histBinX/2)), range=((-pi,pi),(-1,1))."""

@@ -166,6 +166,16 @@ class Context:
     def psum_stride(self, F):
         return int(self.lib.sr_ct_psum_stride(F))
 
+    # ---- resident vectors (sr_vectors.hip) ----
+    def vectors(self, nV, capacity=0):
+        """An empty ResidentVectors object for nV vectors (this rank's columns)."""
+        return ResidentVectors(self, nV, capacity)
+
+    def counter(self, name):
+        v = ctypes.c_uint64()
+        check(self.lib.sr_counter(self.h, name.encode(), ctypes.byref(v)), 'sr_counter')
+        return int(v.value)
+
     # ---- kernel 2 ----
     def rotate_hist(self, vecs, q, edges_phi, edges_cos, v0=0, nV=None, block_len=0, want_outer=True):
         """vecs (N, Vtot, 3) float32 -> hist (nV, nphi, ncos), vecsum (nV,3), outer (nB, nV, 6)."""
@@ -441,3 +451,99 @@ def default_context(device=None):
     if device not in _default or _default[device].h is None:
         _default[device] = Context(device)
     return _default[device]
+
+
+class ResidentVectors:
+    """One rank's columns [v0, v0 + nV) of a (frames, vectors, 3) float32 array on the device: appended chunk by chunk
+    (strided host copies of just those columns, or straight from coordinates through the GPU front end), packed once,
+    then read by C(t) and by the rotation + histogram pass.  sr_vectors_* of include/spinrelax_hip.h."""
+
+    def __init__(self, ctx, nV, capacity=0):
+        self.ctx = ctx
+        self.nV = int(nV)
+        self.h = ctx.lib.sr_vectors_create(ctx.h, self.nV, int(capacity))
+        if not self.h:
+            raise SpinRelaxHipError('sr_vectors_create failed: %s' % _lib.last_error())
+
+    def close(self):
+        if getattr(self, 'h', None) and getattr(self.ctx, 'h', None):
+            self.ctx.lib.sr_vectors_destroy(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def frames(self):
+        return int(self.ctx.lib.sr_vectors_frames(self.h))
+
+    def append(self, vecs, v0=0):
+        """n more frames from a host array (n, Vtot, 3); only columns [v0, v0 + nV) are copied to the device"""
+        vecs = _f32(vecs)
+        if vecs.ndim != 3 or vecs.shape[2] != 3:
+            raise ValueError('vecs must be (frames, vectors, 3)')
+        check(self.ctx.lib.sr_vectors_append_f32(self.ctx.h, self.h, _ptr(vecs), vecs.shape[0], vecs.shape[1], int(v0)),
+              'sr_vectors_append_f32')
+        return self
+
+    def truncate(self, n_frames):
+        check(self.ctx.lib.sr_vectors_truncate(self.ctx.h, self.h, int(n_frames)), 'sr_vectors_truncate')
+
+    def download(self, f0=0, n=None):
+        n = self.frames - f0 if n is None else n
+        out = np.empty((n, self.nV, 3), dtype=np.float32)
+        check(self.ctx.lib.sr_vectors_download_f32(self.ctx.h, self.h, int(f0), int(n), _ptr(out)), 'sr_vectors_download_f32')
+        return out
+
+    def ct(self, R, F, chunk_start=None, mode=0):
+        """calculate_Ct_Palmer (calculate-Ct-from-traj.py:200-238) of the resident vectors: Ct, dCt (F//2, nV) float64"""
+        L = F // 2
+        Ct = np.empty((L, self.nV))
+        dCt = np.empty((L, self.nV))
+        cs = None if chunk_start is None else np.ascontiguousarray(chunk_start, dtype=np.int64)
+        if cs is not None and cs.shape != (R,):
+            raise ValueError('chunk_start must have R entries')
+        check(self.ctx.lib.sr_vectors_ct_f32(self.ctx.h, self.h, int(R), int(F), _ptr(cs), int(mode), _ptr(Ct), _ptr(dCt)),
+              'sr_vectors_ct_f32')
+        return Ct, dCt
+
+    def hist(self, q, edges_phi, edges_cos, block_len=0, N_hist=0, want_outer=True):
+        """rotation + Lambert histogram + vector sums + per-block outer-product sums (calculate-Ct-from-traj.py:541-646) of
+        the first N_hist frames (0 = all): hist (nV, nphi, ncos), vecsum (nV, 3), outer (nB, nV, 6)"""
+        ep = _f64(edges_phi)
+        ec = _f64(edges_cos)
+        nphi, ncos = ep.size - 1, ec.size - 1
+        qq = None if q is None else _f64(q)
+        N = N_hist if N_hist and N_hist > 0 else self.frames
+        hist = np.empty((self.nV, nphi, ncos))
+        vecsum = np.empty((self.nV, 3))
+        Fb = block_len if (block_len and 0 < block_len <= N) else N
+        outer = np.empty((N // Fb, self.nV, 6)) if want_outer else None
+        check(self.ctx.lib.sr_vectors_hist_f32(self.ctx.h, self.h, int(N), _ptr(qq), _ptr(ep), nphi, _ptr(ec), ncos, _ptr(hist),
+                                               _ptr(vecsum), _ptr(outer), int(block_len or 0)), 'sr_vectors_hist_f32')
+        return hist, vecsum, outer
+
+
+def append_xyz(ctx, lab, fit, xyz, indexX, indexH, fit_indices=None, ref_xyz=None):
+    """obtain_XHvecs (+ centring and superposition when fit_indices / ref_xyz are given) of one chunk of coordinates
+    (frames, atoms, 3) on the GPU, appended to the ResidentVectors objects `lab` and / or `fit` (either may be None);
+    indexX / indexH are THIS rank's slice of the selections.  calculate-Ct-from-traj.py:64-86, 462-470."""
+    xyz = _f32(xyz)
+    iX = np.ascontiguousarray(indexX, dtype=np.int32)
+    iH = np.ascontiguousarray(indexH, dtype=np.int32)
+    fi = None if fit_indices is None else np.ascontiguousarray(fit_indices, dtype=np.int32)
+    rx = None if ref_xyz is None else _f32(ref_xyz)
+    check(ctx.lib.sr_vectors_append_xyz_f32(ctx.h, None if lab is None else lab.h, None if fit is None else fit.h, _ptr(xyz),
+                                            xyz.shape[0], xyz.shape[1], _ptr(iX), _ptr(iH), iX.size, _ptr(fi),
+                                            0 if fi is None else fi.size, _ptr(rx)), 'sr_vectors_append_xyz_f32')

@@ -94,6 +94,91 @@ def test_script_from_raw_coordinates_to_Ct(ctx, tmp_path):
     assert np.max(np.abs(np.array(Cx).T / Cl - 1)) < 1e-6
 
 
+def test_mdtraj_loader_streams_chunks_into_resident_vectors(tmp_path):
+    """load_mdtraj of the drop-in script EXECUTED (with tests/fake_mdtraj standing in for the absent MDTraj: it reads files
+    and resolves selections, nothing else): two trajectory files read in --split chunks of 128 frames, every chunk's
+    coordinates turned into bond vectors + superposition on the GPU and appended to the rank's resident vectors, each
+    file's tail cut to whole blocks of memory time.  The files must equal, byte for byte, what the same script writes from
+    the same coordinates given as .npz arrays (the whole-array path)."""
+    s = synth.config_shapes(1)
+    F = int(s['tau_memory'] / s['dt'])
+    d1 = synth.synth_coordinates(5 * F + 37, 12, 31)                 # 37 and 63 frames of tail to drop
+    d2 = synth.synth_coordinates(3 * F + 63, 12, 32)
+    natoms = d1['xyz'].shape[1]
+    resseq = np.zeros(natoms, dtype=int)
+    resseq[d1['indexH']] = np.arange(2, 14)
+    sel = {'sel:name H': d1['indexH'], 'sel:name N and not resname PRO': d1['indexX'], 'sel:name CA': d1['fit_indices']}
+    np.savez(str(tmp_path / 'ref.npz'), xyz=d1['ref_xyz'][None], resseq=resseq, dt=s['dt'], **sel)
+    outs = {}
+    for mode in ('mdtraj', 'arrays'):
+        files = []
+        for k, d in enumerate((d1, d2)):
+            fn = str(tmp_path / ('%s_%d.%s' % (mode, k, 'xtc.npz' if mode == 'mdtraj' else 'npz')))
+            if mode == 'mdtraj':
+                np.savez(fn, xyz=d['xyz'], resseq=resseq, dt=s['dt'], **sel)
+                fn2 = fn[:-4]                                             # a name that does not end in .npz: the MDTraj branch
+                os.rename(fn, fn2)
+                fn = fn2
+            else:
+                np.savez(fn, xyz=d['xyz'], ref_xyz=d1['ref_xyz'], indexX=d['indexX'], indexH=d['indexH'],
+                         fit_indices=d1['fit_indices'], names=np.arange(2, 14), dt=s['dt'])
+            files.append(fn)
+        out = str(tmp_path / ('o_' + mode))
+        cmd = [sys.executable, os.path.join(ROOT, 'scripts', 'calculate-Ct-from-traj.py'), '-s', str(tmp_path / 'ref.npz'), '-f'] + files + \
+              ['--tau', str(s['tau_memory']), '-o', out, '--Ct', '--vecHist', '--binary', '--vecAvg', '--S2', '--fitsel', 'name CA',
+               '--vecRot', '0.866165 0.392069 -0.308123 -0.033159']
+        env = dict(os.environ)
+        if mode == 'mdtraj':
+            cmd += ['--split', '128']
+            env['PYTHONPATH'] = os.path.join(ROOT, 'tests', 'fake_mdtraj') + os.pathsep + env.get('PYTHONPATH', '')
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
+        assert p.returncode == 0, p.stdout.decode()[-3000:]
+        if mode == 'mdtraj':
+            assert b'%d frames read, %d kept' % (5 * F + 37, 5 * F) in p.stdout and b'%d frames read, %d kept' % (3 * F + 63, 3 * F) in p.stdout
+        outs[mode] = out
+    for suffix in ('_Ctext.dat', '_Ctint.dat', '_avgvec.dat', '_S2.dat'):
+        a, b = open(outs['mdtraj'] + suffix, 'rb').read(), open(outs['arrays'] + suffix, 'rb').read()
+        assert a == b and len(a) > 100, suffix
+    za, zb = np.load(outs['mdtraj'] + '_vecHistogram.npz', allow_pickle=True), np.load(outs['arrays'] + '_vecHistogram.npz', allow_pickle=True)
+    assert np.array_equal(za['data'], zb['data']) and za['data'].sum() == 8 * F * 12
+
+
+def test_host_vector_uploads_move_only_the_ranks_columns(ctx):
+    """a rank receives all frames of ITS vector slice -- a strided copy, row pitch 12 V, width 12 nV.
+    The library counts what goes through that copy: the host-pointer entry points and the resident-vector path move
+    exactly 12 N nV bytes per vector set, once, whatever the width of the host array."""
+    e = hostct.lambert_edges()
+    N, V, v0, nV, F = 6 * 256, 40, 13, 11, 256
+    vecs = synth.synth_vectors(N, V, seed=90)
+    b0, c0 = ctx.counter('h2d_vector_bytes'), ctx.counter('vector_uploads')
+    Ct, dCt = ctx.ct_palmer(vecs, 6, F, v0=v0, nV=nV)
+    assert ctx.counter('h2d_vector_bytes') - b0 == 12 * N * nV and ctx.counter('vector_uploads') - c0 == 1
+    full, dfull = ctx.ct_palmer(vecs, 6, F)
+    assert np.array_equal(Ct, full[:, v0:v0 + nV]) and np.array_equal(dCt, dfull[:, v0:v0 + nV])
+    b1 = ctx.counter('h2d_vector_bytes')
+    hist, vsum, outer = ctx.rotate_hist(vecs, np.array(synth.Q_EXT), e[0], e[1], v0=v0, nV=nV, block_len=F)
+    assert ctx.counter('h2d_vector_bytes') - b1 == 12 * N * nV
+    # resident vectors: two files with tails, ONE pass over PCIe, then C(t) and the vector distribution from the same planes
+    a, b = synth.synth_vectors(3 * F + 17, V, seed=91), synth.synth_vectors(2 * F + 200, V, seed=92)
+    b2, c2 = ctx.counter('h2d_vector_bytes'), ctx.counter('vector_uploads')
+    rv = ctx.vectors(nV)
+    rv.append(a[:3 * F], v0=v0)
+    rv.append(b[:2 * F], v0=v0)
+    assert rv.frames == 5 * F
+    Ct2, dCt2 = rv.ct(5, F)
+    h2, s2, o2 = rv.hist(np.array(synth.Q_EXT), e[0], e[1], block_len=F)
+    assert ctx.counter('h2d_vector_bytes') - b2 == 12 * 5 * F * nV and ctx.counter('vector_uploads') - c2 == 2
+    cat = np.ascontiguousarray(np.concatenate([a[:3 * F], b[:2 * F]]))
+    Ct3, dCt3 = ctx.ct_palmer(cat, 5, F, v0=v0, nV=nV)
+    h3, s3, o3 = ctx.rotate_hist(cat, np.array(synth.Q_EXT), e[0], e[1], v0=v0, nV=nV, block_len=F)
+    assert np.array_equal(Ct2, Ct3) and np.array_equal(dCt2, dCt3) and np.array_equal(h2, h3) and np.array_equal(s2, s3) and np.array_equal(o2, o3)
+    assert np.array_equal(rv.download(F, 7), cat[F:F + 7, v0:v0 + nV])
+    rv.truncate(4 * F)
+    Ct4, _ = rv.ct(4, F)
+    assert np.array_equal(Ct4, ctx.ct_palmer(cat[:4 * F], 4, F, v0=v0, nV=nV)[0])
+    rv.close()
+
+
 def test_round2_entry_points_refuse_bad_arguments(ctx):
     """Shapes and index ranges are checked on the host before anything is launched (a kernel fed an out-of-range atom
     index or lag would fault): every refusal is a SpinRelaxHipError carrying the library's message."""

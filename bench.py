@@ -102,6 +102,7 @@ def parse():
     ap.add_argument('--ct-fft', type=int, default=-1, help='kernel 1: 2 = real-input FFT (k_ct_rfft) where it applies, 1 = complex FFT (k_ct_fft), 0 = direct (k_ct_palmer); -1 = library default (2)')
     ap.add_argument('--depth', type=int, default=5, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cli-wall', action='store_true', help='skip the wall-clock run of the drop-in CLI chain (run-all.bash Step 3 + Step 4) on the same workload')
     ap.add_argument('--no-kernel-profile', action='store_true', help='skip the per-kernel alone / saturated timings after the timed region (the `kernels` entries then only carry in-pipeline durations)')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
     ap.add_argument('--all-ranks-on-device0', action='store_true', help='rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)')
@@ -198,6 +199,54 @@ def cpu_baseline(vecs_host, s, cfg, nv1, nvall):
                                 sample='%d vectors (%.0f MB, not cache-resident), %.2f s' % (nva, v4c.nbytes / 1e6, dt2))
     except Exception as exc:                                 # the extra figure is optional
         out['all_cores'] = dict(error=str(exc))
+    return out
+
+
+def cli_wall(vecs_host, s, cfg, cpu):
+    """Wall time of the PRODUCT: the drop-in scripts of run-all.bash Step 3 + Step 4 (run-all.bash:476-516) as subprocesses on
+    the same synthetic trajectory, from a vector file on disk to the R1/R2/NOE tables -- process start-up, file reading,
+    the one strided upload, the kernels, the reference's text writers and all.  Beside it the reference algorithm's time for
+    the same chain, extrapolated from the cpu_baseline sample (1 thread, as the reference runs)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from spinrelax_amd import synth
+    tmp = tempfile.mkdtemp(prefix='sr_cli_')
+    scr = os.path.join(ROOT, 'scripts')
+    out = {}
+    try:
+        t0 = time.time()
+        fn = os.path.join(tmp, 'vecs.npy')
+        np.save(fn, vecs_host)
+        out['write_input_s'] = time.time() - t0
+        pref = os.path.join(tmp, 'rotdif')
+        steps = [('calculate-Ct-from-traj', ['calculate-Ct-from-traj.py', '-s', 'reference.pdb', '-f', fn, '--dt', str(s['dt']), '--tau', str(s['tau_memory']),
+                                             '-o', pref, '--vecHist', '--binary', '--vecAvg', '--S2', '--Ct'] +
+                  (['--vecRot', ' '.join('%.6f' % x for x in synth.Q_EXT)] if cfg == 3 else [])),
+                 ('calculate-fitted-Ct', ['calculate-fitted-Ct.py', '-f', pref + '_Ctint.dat', '-o', pref]),
+                 ('calculate-relaxations-from-Ct', ['calculate-relaxations-from-Ct.py', '-f', pref + '_fittedCt.dat', '-o', pref + '-600', '-F', '%ge6' % synth.FIELD_MHZ,
+                                                    '--tu', 'ps', '--zeta', str(synth.ZETA)] +
+                  (['--distfn', pref + '_vecHistogram.npz', '-D', '%g %g' % (synth.DISO, synth.DANI)] if cfg == 3 else ['-D', '%g' % synth.DISO]))]
+        total = 0.0
+        for name, cmd in steps:
+            t0 = time.time()
+            p = subprocess.run([sys.executable, os.path.join(scr, cmd[0])] + cmd[1:], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+            dt = time.time() - t0
+            if p.returncode != 0:
+                out['error'] = '%s failed: %s' % (name, p.stdout.decode()[-500:])
+                return out
+            out[name + '_s'] = round(dt, 3)
+            total += dt
+        out['total_s'] = round(total, 3)
+        out['files'] = sorted(os.path.basename(f) for f in os.listdir(tmp) if f.startswith('rotdif'))
+        out['note'] = ('three python processes (interpreter + library start-up each), input read from a %.0f MB .npy, ONE strided upload of the vectors, '
+                       'outputs through the reference-format text writers' % (vecs_host.nbytes / 1e6))
+        if cpu and cpu.get('value'):
+            triples = synth.exact_triples(s['R'], s['F'], vecs_host.shape[1])
+            out['cpu_reference_chain_s_extrapolated'] = round(triples / cpu['value'], 1)
+            out['cpu_note'] = 'exact triples of the workload / the 1-thread whole-path rate of cpu_baseline (a %s-vector sample)' % cpu.get('sample', '?').split(' of the')[0][-3:].strip()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     return out
 
 
@@ -587,6 +636,8 @@ def main():
             res['cpu_baseline'] = cpu_baseline(vecs_host, s, cfg, min(args.cpu_sample_vectors, V), min(args.cpu_allcore_vectors, V))
         else:
             res['cpu_baseline'] = None
+        if world == 1 and not args.no_cli_wall:
+            res['cli_wall_s'] = cli_wall(vecs_host, s, cfg, res['cpu_baseline'])
         print(json.dumps(res))
     # deterministic teardown while the HIP runtime is alive: streams, pinned mirrors and the context's work areas go
     # here, not in __del__ / static destructors at interpreter exit

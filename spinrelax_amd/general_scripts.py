@@ -118,18 +118,80 @@ def print_xylist(fn, x, ylist, bCols=False, header=""):
                     print("&", file=fp)
 
 
+def _numpy_str_pairs(y):
+    """str(row).strip('[]') for every row of a float64 array of shape (n, 2), as numpy's array printer formats a
+    two-element float64 vector (numpy/_core/arrayprint.py FloatingFormat, default print options: precision 8, floatmode
+    'maxprec') -- but for all rows at once instead of one array2string call per line (which is what made writing the two
+    C(t) files of a 512-residue run take 30 s).  Per row: scientific notation when the largest magnitude is >= 1e8, the
+    smallest non-zero one < 1e-4 or their ratio > 1000, positional otherwise; digits = shortest round-trip digits, at
+    most 8 after the point, trailing zeros dropped; both elements padded to common widths on either side of the point.
+    Rows this function is not sure about (non-finite values, three-digit exponents) are formatted by numpy itself.
+    tests/test_formats_and_hostlogic.py compares it with numpy's own output on a few hundred thousand pairs."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    n = y.shape[0]
+    out = np.empty(n, dtype=object)
+    a = np.abs(y)
+    finite = np.isfinite(y).all(axis=1)
+    nz = a > 0
+    big = np.where(nz, a, 0.0).max(axis=1)
+    small = np.where(nz, a, np.inf).min(axis=1)
+    with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+        expf = nz.any(axis=1) & ((big >= 1e8) | (small < 1e-4) | (big / small > 1000.0))
+    slow = ~finite | (expf & ((big >= 1e100) | (small < 1e-99)))
+    pos = finite & ~expf & ~slow
+    if pos.any():
+        idx = np.nonzero(pos)[0]
+        s8 = np.char.rstrip(np.char.mod('%.8f', y[idx]), '0')                 # '0.12345678', '12.', '-0.5'
+        dot = np.char.find(s8, '.')
+        ln = np.char.str_len(s8)
+        frac = ln - dot - 1
+        padl = dot.max(axis=1, keepdims=True) - dot
+        padr = frac.max(axis=1, keepdims=True) - frac
+        e = np.char.ljust(np.char.rjust(s8, ln + padl), ln + padl + padr)
+        out[idx] = np.char.add(np.char.add(e[:, 0], ' '), e[:, 1])
+    ex = finite & expf & ~slow
+    if ex.any():
+        idx = np.nonzero(ex)[0]
+        s8 = np.char.mod('%.8e', y[idx])                                       # '-1.23400000e-05'
+        epos = np.char.find(s8, 'e')
+        mant = np.char.rstrip(np.array([[u[:k] for u, k in zip(r, kk)] for r, kk in zip(s8, epos)]), '0')
+        dot = np.char.find(mant, '.')
+        prec = (np.char.str_len(mant) - dot - 1).max(axis=1)                   # digits after the point, common to the row
+        rows = np.empty(idx.size, dtype=object)
+        for p in np.unique(prec):
+            sel = np.nonzero(prec == p)[0]
+            sp = np.char.mod('%%.%de' % p, y[idx[sel]])
+            if p == 0:                                                         # C prints '1e-05', numpy keeps the point: '1.e-05'
+                sp = np.char.replace(sp, 'e', '.e')
+            d2 = np.char.find(sp, '.')
+            padl = d2.max(axis=1, keepdims=True) - d2
+            e = np.char.rjust(sp, np.char.str_len(sp) + padl)
+            rows[sel] = np.char.add(np.char.add(e[:, 0], ' '), e[:, 1])
+        out[idx] = rows
+    for j in np.nonzero(slow)[0]:
+        out[j] = str(y[j]).strip('[]')
+    return out
+
+
 def print_sxylist(fn, legend, x, ylist, header=[]):
     """general_scripts.py:275-290 -- the `_Ctint.dat` / `_Ctext.dat` writer: per set `@s<i> legend "<name>"`,
     then `x[j] <numpy str of ylist[i][j] without brackets>`, then `&`.  The numeric text is whatever numpy's
-    str() gives for the array dtype (8 significant digits), exactly like the reference."""
+    str() gives for the array dtype (8 significant digits), exactly like the reference; (n, 2) float64 sets (C(t) with its
+    error) are formatted a whole set at a time (_numpy_str_pairs), anything else line by line through numpy."""
     ylist = np.array(ylist)
+    xs = [str(v) for v in x]
+    fast = ylist.dtype == np.float64 and ylist.ndim == 3 and ylist.shape[2] == 2
     with open(fn, 'w') as fp:
         for line in header:
             print("%s" % line, file=fp)
         for i in range(len(ylist)):
             print("@s%d legend \"%s\"" % (i, legend[i]), file=fp)
-            for j in range(len(x)):
-                print(x[j], str(ylist[i][j]).strip('[]'), file=fp)
+            if fast:
+                ys = _numpy_str_pairs(ylist[i])
+                fp.write(''.join('%s %s\n' % (a, b) for a, b in zip(xs, ys)))
+            else:
+                for j in range(len(x)):
+                    print(x[j], str(ylist[i][j]).strip('[]'), file=fp)
             print("&", file=fp)
 
 

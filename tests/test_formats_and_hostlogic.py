@@ -223,3 +223,25 @@ def test_plumed_colvar_reader_rejects_malformed(tmp_path):
     bad.write_text('#! FIELDS time a b\n 0.0 1.0 2.0\n')
     with pytest.raises(ValueError):
         plumedcolvario.read_qorient(str(bad))
+
+
+def test_fast_pair_formatter_equals_numpy_str():
+    """general_scripts._numpy_str_pairs formats the "<Ct> <dCt>" part of every _Ctint.dat line for a whole residue at once;
+    the reference writes str(np.array([Ct, dCt])).strip('[]') per line (general_scripts.py:283-289).  Same text, always:
+    positional and scientific rows, padding on both sides of the point, signs, zeros, exact decimals, the 1e-4 / 1e8 / ratio
+    1000 switch points, and the rows it hands back to numpy (non-finite values, three-digit exponents)."""
+    from spinrelax_amd import general_scripts as gs
+    rng = np.random.RandomState(1)
+    n = 20000
+    sets = [np.stack((rng.rand(n), rng.rand(n) * 1e-2), -1), np.stack((rng.rand(n), rng.rand(n) * 1e-4), -1),
+            np.stack((rng.rand(n) * 2 - 1, 10.0 ** rng.uniform(-12, 9, n) * rng.choice([-1, 1], n)), -1)]
+    sp = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 0.25, 1e-4, 9.9999e-5, 1e-5, 1e8, 99999999.0, 123456789.0, 1e3, 999.9, 1000.1, 0.1,
+                   0.123456785, 0.123456775, 1.23449999999e-3, 2.5, 1 / 3., 2 / 3., 1e-100, 1e100, 1e-99, np.nan, np.inf, -np.inf,
+                   7.0, 1e22, 5e-324, 123.456])
+    sets.append(np.array([(a, b) for a in sp for b in sp]))
+    dec = rng.randint(0, 9, n)
+    sets.append(np.stack([np.round(rng.rand(n), d) for d in range(9)], 0)[dec, np.arange(n)][:, None] * 10.0 ** rng.randint(-6, 6, (n, 2)))
+    for y in sets:
+        fast = gs._numpy_str_pairs(y)
+        for j in range(len(y)):
+            assert fast[j] == str(y[j]).strip('[]'), (y[j], fast[j])

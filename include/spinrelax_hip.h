@@ -191,6 +191,12 @@ int sr_vectors_append_xyz_f32(sr_ctx *, sr_vectors *lab, sr_vectors *fit, const 
 int sr_vectors_download_f32(sr_ctx *, const sr_vectors *, int64_t f0, int64_t n, float *out_host);
 int sr_vectors_ct_f32(sr_ctx *, sr_vectors *, int64_t R, int64_t F, const int64_t *chunk_start_host, int mode,
                       double *Ct, double *dCt);
+/* Fewer vectors than GPUs: ranks own ranges of CHUNKS instead (last paragraph).  A rank computes the
+ * raw sums S[v][r][d-1] = sum_j (u_j . u_{j+d})^2 of ITS chunks, (nV, R, L) float64 on the host; the gathered (nV, R_total, L)
+ * array goes through the same mean / std kernel that finishes a single-process run (calculate-Ct-from-traj.py:226-228: mean
+ * and two-pass std over the replicates need every replicate's value, not running sums). */
+int sr_vectors_ct_sums_f32(sr_ctx *, sr_vectors *, int64_t R, int64_t F, const int64_t *chunk_start_host, int mode, double *sums);
+int sr_ct_finalize_sums_f64(sr_ctx *, const double *sums_host, int64_t R, int64_t F, int64_t nV, double *Ct, double *dCt);
 int sr_vectors_hist_f32(sr_ctx *, sr_vectors *, int64_t N_hist, const double *q, const double *edges_phi, int nphi,
                         const double *edges_cos, int ncos, double *hist, double *vecsum, double *outer, int64_t block_len);
 int sr_counter(sr_ctx *, const char *name, uint64_t *value);

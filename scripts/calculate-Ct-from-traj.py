@@ -197,7 +197,7 @@ def main():
             sys.exit(1)
         return int(tau_memory / dt)
 
-    host_fit = None          # host copy of the fitted vectors (vector-file input only; the --vecDist listing needs it)
+    host_fit = host_lab = None   # host copies of the vectors (vector-file input only: the --vecDist listing and the chunk-sharded C(t) need them)
     if all(f.endswith('.npy') or f.endswith('.npz') for f in args.infn):
         resXH, vecXH, vecXHfit, deltaT = load_vector_files(args.infn, args.dt)
         if args.qfile is not None:
@@ -217,15 +217,23 @@ def main():
         # ONE upload per vector set, of this rank's columns only; when the file holds no separate lab-frame vectors the two
         # sets are the same arrays and share the resident copy
         same = all(a is b for a, b in zip(vecXH, vecXHfit)) and len(vecXH) == len(vecXHfit)
+        # fewer vectors than ranks: C(t) is sharded over the replicate chunks instead; the vector
+        # distribution keeps the vector sharding (the surplus ranks idle there)
+        repl = args.bDoCt and srdist.replicate_sharding(vecXHfit[0].shape[1])
         rv_fit, V, i0, N = hostct.upload_shard(vecXHfit, F)
-        rv_lab = rv_fit if same or not args.bDoCt else hostct.upload_shard(vecXH, F)[0]
-        host_fit = vecXHfit
+        rv_lab = rv_fit if same or not args.bDoCt or repl else hostct.upload_shard(vecXH, F)[0]
+        host_fit, host_lab = vecXHfit, vecXH
         del vecXH
     else:
         if args.qfile is not None:
             print("= = = ERROR: --qfile works on vector-file input (.npy/.npz), not on MDTraj input.", file=sys.stderr)
             sys.exit(1)
         resXH, rv_lab, rv_fit, deltaT, V, i0, N = load_mdtraj(args, frames_per_chunk_of)
+        repl = False
+        if srdist.replicate_sharding(V):
+            print("= = = ERROR: %i ranks for %i vectors: trajectory input is sharded by vector; use at most %i ranks (vector-file "
+                  "input can shard the replicate chunks instead)." % (srdist.world(), V, V), file=sys.stderr)
+            sys.exit(1)
         F = frames_per_chunk_of(deltaT)
         if N < 1:
             print("= = = ERROR: no trajectory holds a full block of memory time tau!", file=sys.stderr)
@@ -244,10 +252,16 @@ def main():
         print("= = = Conducting Ct_external using Palmer's approach.")
         print("= = = timestep: ", deltaT, "ps")
         print("= = = tau_memory: ", tau_memory, "ps")
-        Ct, dCt = hostct.calculate_Ct_resident(rv_lab, V, R, F, mode=mode)
+        if repl:
+            Ct, dCt = hostct.calculate_Ct_chunk_sharded(host_lab, F, mode=mode)
+        else:
+            Ct, dCt = hostct.calculate_Ct_resident(rv_lab, V, R, F, mode=mode)
         gs.print_sxylist(out_pref + '_Ctext.dat', resXH, dt, np.stack((Ct.T, dCt.T), axis=-1))
         print("= = = Conducting Ct_internal using Palmer's approach.")
-        if rv_fit is not rv_lab:
+        if repl:
+            if not same:
+                Ct, dCt = hostct.calculate_Ct_chunk_sharded(host_fit, F, mode=mode)
+        elif rv_fit is not rv_lab:
             Ct, dCt = hostct.calculate_Ct_resident(rv_fit, V, R, F, mode=mode)
         gs.print_sxylist(out_pref + '_Ctint.dat', resXH, dt, np.stack((Ct.T, dCt.T), axis=-1))
     if rv_lab is not None and rv_lab is not rv_fit:

@@ -97,6 +97,8 @@ SIGNATURES = {
                                           c_void_p, c_int, c_void_p]),
     'sr_vectors_download_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'sr_vectors_ct_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
+    'sr_vectors_ct_sums_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p]),
+    'sr_ct_finalize_sums_f64': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     'sr_vectors_hist_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                     c_void_p, c_int64]),
     'sr_counter': (c_int, [c_void_p, c_char_p, POINTER(ctypes.c_uint64)]),

@@ -238,6 +238,48 @@ int sr_vectors_ct_f32(sr_ctx *ctx, sr_vectors *h, int64_t R, int64_t F, const in
     return 0;
 }
 
+/* raw sums S[v][r][d-1] = sum_j (u_j . u_{j+d})^2 per (vector, chunk, lag) on the HOST, (nV, R, L) compact: what a rank that
+ * owns a range of CHUNKS (replicates) contributes when there are fewer vectors than GPUs */
+int sr_vectors_ct_sums_f32(sr_ctx *ctx, sr_vectors *h, int64_t R, int64_t F, const int64_t *chunk_start_host, int mode, double *sums)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(h && sums, -2, "sr_vectors_ct_sums_f32: null pointer");
+    SR_REQUIRE(R >= 1 && F >= 2, -3, "sr_vectors_ct_sums_f32: bad shape R=%lld F=%lld", (long long)R, (long long)F);
+    if (int rc = pack(ctx, h)) return rc;
+    const int64_t L = F / 2, Lp = sr_ct_psum_stride(F);
+    double *psum = (double *)sr_workspace(ctx, SR_WS_PSUM, (size_t)(h->nV * R * Lp) * sizeof(double));
+    if (!psum) return -5;
+    if (!chunk_start_host) SR_REQUIRE(R * F <= h->N, -3, "sr_vectors_ct_sums_f32: R*F=%lld exceeds the %lld frames held", (long long)(R * F), (long long)h->N);
+    int rc = sr_ct_palmer_sums_f32_dev(ctx, h->soa, h->Npad, R, F, h->nV, chunk_start_host, mode, psum);
+    if (rc) return rc;
+    SR_HIP(hipMemcpy2DAsync(sums, (size_t)L * sizeof(double), psum + 1, (size_t)Lp * sizeof(double), (size_t)L * sizeof(double),
+                            (size_t)(h->nV * R), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+/* mean / std over the R replicate chunks (calculate-Ct-from-traj.py:226-228) from HOST raw sums (nV, R, L) -- the SAME kernel
+ * that finishes a single-process run, so the root of a replicate-sharded run gets the single-process bits */
+int sr_ct_finalize_sums_f64(sr_ctx *ctx, const double *sums, int64_t R, int64_t F, int64_t nV, double *Ct, double *dCt)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(sums && Ct && dCt, -2, "sr_ct_finalize_sums_f64: null pointer");
+    SR_REQUIRE(R >= 1 && F >= 2 && nV >= 1, -3, "sr_ct_finalize_sums_f64: bad shape");
+    const int64_t L = F / 2, Lp = sr_ct_psum_stride(F);
+    double *psum = (double *)sr_workspace(ctx, SR_WS_PSUM, (size_t)(nV * R * Lp) * sizeof(double));
+    double *Ct_d = (double *)sr_workspace(ctx, SR_WS_OUT0, (size_t)(L * nV) * sizeof(double));
+    double *dCt_d = (double *)sr_workspace(ctx, SR_WS_OUT1, (size_t)(L * nV) * sizeof(double));
+    if (!psum || !Ct_d || !dCt_d) return -5;
+    SR_HIP(hipMemcpy2DAsync(psum + 1, (size_t)Lp * sizeof(double), sums, (size_t)L * sizeof(double), (size_t)L * sizeof(double),
+                            (size_t)(nV * R), hipMemcpyHostToDevice, ctx->stream));
+    int rc = sr_ct_finalize_f64_dev(ctx, psum, R, F, nV, Ct_d, dCt_d);
+    if (rc) return rc;
+    SR_HIP(hipMemcpyAsync(Ct, Ct_d, (size_t)(L * nV) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(dCt, dCt_d, (size_t)(L * nV) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int sr_vectors_hist_f32(sr_ctx *ctx, sr_vectors *h, int64_t N_hist, const double *q, const double *edges_phi, int nphi,
                         const double *edges_cos, int ncos, double *hist, double *vecsum, double *outer, int64_t block_len)
 {

@@ -120,6 +120,41 @@ def upload_shard(vec_list, frames_per_chunk=None, ctx=None):
     return rv, V, i0, N
 
 
+def chunk_table(vec_list, F):
+    """(file index, first frame) of every whole chunk of F frames, in the order reformat_vecs_by_tau concatenates them."""
+    return [(i, c * F) for i, v in enumerate(vec_list) for c in range(v.shape[0] // F)]
+
+
+def calculate_Ct_chunk_sharded(vec_list, F, mode=0, ctx=None, sums_fn=None, finalize_fn=None):
+    """C(t) with the replicate CHUNKS sharded over the ranks (fewer vectors than GPUs): this rank uploads the frames of its
+    chunk range -- all vectors --, computes their raw sums, the (V, R, L) sums of all ranks are gathered and every rank
+    runs the single-process mean / std kernel on them: the same bits as one process.
+    sums_fn(list of (F, V, 3) chunks) -> (V, n, L) and finalize_fn((V, R, L)) -> (Ct, dCt) replace the GPU calls in the
+    CPU test of the sharding logic (tests/test_cabi_and_dist.py)."""
+    table = chunk_table(vec_list, F)
+    R = len(table)
+    if R < 1:
+        print("= = = ERROR: no trajectory holds a full block of memory time tau!", file=sys.stderr)
+        sys.exit(1)
+    V = vec_list[0].shape[1]
+    L = F // 2
+    r0, nR = srdist.my_chunk_range(R)
+    mine = [vec_list[i][f0:f0 + F] for i, f0 in table[r0:r0 + nR]]
+    if nR == 0:
+        sums = np.empty((V, 0, L))
+    elif sums_fn is not None:
+        sums = sums_fn(mine)
+    else:
+        with _ctx(ctx).vectors(V, nR * F) as rv:
+            for c in mine:
+                rv.append(c)
+            sums = rv.ct_sums(nR, F, mode=mode)
+    sums = srdist.gather_chunk_axis(sums, R)
+    if finalize_fn is not None:
+        return finalize_fn(sums)
+    return _ctx(ctx).ct_finalize_sums(sums, F)
+
+
 def calculate_Ct_resident(rv, V, R, F, mode=0):
     """calculate_Ct_Palmer of resident vectors (regular chunks r*F: the unused tails were dropped at upload); all ranks
     receive the whole (lags, V) arrays."""

@@ -119,6 +119,19 @@ def my_range(n):
     return shard_range(n, rank(), world())
 
 
+def replicate_sharding(V):
+    """True when there are fewer vectors than ranks: C(t) is then sharded over the replicate CHUNKS instead (every rank all
+    vectors of its chunk range), the per-replicate values are gathered and the mean / two-pass std over the replicates is
+    formed from all of them (calculate-Ct-from-traj.py:226-228; an all-reduce of sums and squares would round dC(t)
+    differently) -- SURVEY.md section 8(e), last paragraph."""
+    return world() > 1 and V < world()
+
+
+def my_chunk_range(R):
+    """Chunks [r0, r0 + nR) of this rank out of R."""
+    return shard_range(R, rank(), world())
+
+
 def _collective_device():
     import torch
     import torch.distributed as dist
@@ -132,6 +145,13 @@ def gather_rows(local, n, axis=0):
     if world() == 1:
         return local
     return gather_vector_axis(np.ascontiguousarray(local), n, axis, device=_collective_device())
+
+
+def gather_chunk_axis(local, R):
+    """All-gather of (V, nR, L) raw sums along the chunk axis (my_chunk_range(R) per rank) -> (V, R, L) on every rank."""
+    if world() == 1:
+        return local
+    return gather_vector_axis(np.ascontiguousarray(local), R, 1, device=_collective_device())
 
 
 _SCRATCH = []

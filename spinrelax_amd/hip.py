@@ -176,6 +176,17 @@ class Context:
         check(self.lib.sr_counter(self.h, name.encode(), ctypes.byref(v)), 'sr_counter')
         return int(v.value)
 
+    def ct_finalize_sums(self, sums, F):
+        """mean / std over the replicates from raw sums (nV, R, F//2): Ct, dCt (F//2, nV) -- the kernel of a single-process run"""
+        sums = _f64(sums)
+        nV, R, L = sums.shape
+        if L != F // 2:
+            raise ValueError('sums must be (vectors, chunks, F//2)')
+        Ct = np.empty((L, nV))
+        dCt = np.empty((L, nV))
+        check(self.lib.sr_ct_finalize_sums_f64(self.h, _ptr(sums), R, int(F), nV, _ptr(Ct), _ptr(dCt)), 'sr_ct_finalize_sums_f64')
+        return Ct, dCt
+
     # ---- kernel 2 ----
     def rotate_hist(self, vecs, q, edges_phi, edges_cos, v0=0, nV=None, block_len=0, want_outer=True):
         """vecs (N, Vtot, 3) float32 -> hist (nV, nphi, ncos), vecsum (nV,3), outer (nB, nV, 6)."""
@@ -517,6 +528,14 @@ class ResidentVectors:
         check(self.ctx.lib.sr_vectors_ct_f32(self.ctx.h, self.h, int(R), int(F), _ptr(cs), int(mode), _ptr(Ct), _ptr(dCt)),
               'sr_vectors_ct_f32')
         return Ct, dCt
+
+    def ct_sums(self, R, F, chunk_start=None, mode=0):
+        """raw sums S[v, r, d-1] = sum_j (u_j . u_{j+d})^2 of the R chunks held, (nV, R, F//2) float64 (replicate sharding)"""
+        sums = np.empty((self.nV, R, F // 2))
+        cs = None if chunk_start is None else np.ascontiguousarray(chunk_start, dtype=np.int64)
+        check(self.ctx.lib.sr_vectors_ct_sums_f32(self.ctx.h, self.h, int(R), int(F), _ptr(cs), int(mode), _ptr(sums)),
+              'sr_vectors_ct_sums_f32')
+        return sums
 
     def hist(self, q, edges_phi, edges_cos, block_len=0, N_hist=0, want_outer=True):
         """rotation + Lambert histogram + vector sums + per-block outer-product sums (calculate-Ct-from-traj.py:541-646) of

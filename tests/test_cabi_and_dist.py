@@ -167,3 +167,73 @@ def test_distributed_relax_and_row_gather_three_ranks():
         assert np.array_equal(got[0], want) and got[1] is None and got[2].shape == (E, n, 12)
         assert np.array_equal(rows, np.arange(n * 2.0).reshape(n, 2))
         assert (pref == '/x/out') == (rank == 0) and pref.endswith('out')
+
+
+def _chunk_worker(rank, world, port, q):
+    import os
+    import sys
+    import numpy as np
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import sr_oracle as o
+    from spinrelax_amd import synth, ct as hostct, dist as srdist
+    F, V = 100, 3
+    files = [synth.synth_vectors(437, V, seed=41), synth.synth_vectors(290, V, seed=42)]        # 4 + 2 chunks, tails dropped
+    assert srdist.replicate_sharding(V) and not srdist.replicate_sharding(world)
+
+    def sums_fn(chunks):                 # the oracle stands in for kernel 1: raw sums per (vector, chunk, lag)
+        v4 = np.stack(chunks).astype(np.float64)
+        return np.stack([np.einsum('rjv,rjv->vr', *(2 * [np.einsum('rjvk,rjvk->rjv', v4[:, :-d], v4[:, d:])])) for d in range(1, F // 2 + 1)], -1)
+
+    def finalize_fn(sums):               # calculate-Ct-from-traj.py:225-228 on ALL replicates
+        n = F - np.arange(1, F // 2 + 1)
+        p = 1.5 * sums / n - 0.5                                   # (V, R, L)
+        return np.mean(p, axis=1).T, (np.std(p, axis=1) / (np.sqrt(p.shape[1]) - 1.0)).T
+
+    r0, nR = srdist.my_chunk_range(6)
+    Ct, dCt = hostct.calculate_Ct_chunk_sharded(files, F, sums_fn=sums_fn, finalize_fn=finalize_fn)
+    q.put((rank, r0, nR, Ct, dCt))
+    srdist.finish()
+
+
+def test_replicate_chunk_sharding_four_ranks_three_vectors():
+    """Fewer vectors than ranks (V = 3, world = 4; SURVEY.md section 8(e), last paragraph): the ranks own ranges of the six
+    replicate chunks (2 / 2 / 1 / 1, cut from two files whose tails are dropped), the per-replicate raw sums are gathered
+    along the chunk axis and mean / two-pass std over ALL replicates are formed from them (calculate-Ct-from-traj.py:225-228)
+    -- every rank gets, bit for bit, what one process computes from the whole array.  (The oracle stands in for kernel 1
+    and for the chunk-statistics kernel; tests/test_gpu_multirank.py runs the same plumbing with the real kernels.)"""
+    import multiprocessing as mp
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import sr_oracle as o
+    from spinrelax_amd import synth
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 4
+    ps = [ctx.Process(target=_chunk_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [(0, 2), (2, 2), (4, 1), (5, 1)]
+    F, V = 100, 3
+    files = [synth.synth_vectors(437, V, seed=41), synth.synth_vectors(290, V, seed=42)]
+    v4 = o.reformat_vecs_by_tau(files, 1.0, float(F)).astype(np.float64)
+    assert v4.shape == (6, F, V, 3)
+    # one process, same arithmetic on the whole array
+    n = F - np.arange(1, F // 2 + 1)
+    sums = np.stack([np.einsum('rjv,rjv->vr', *(2 * [np.einsum('rjvk,rjvk->rjv', v4[:, :-d], v4[:, d:])])) for d in range(1, F // 2 + 1)], -1)
+    p = 1.5 * sums / n - 0.5
+    Ct1, dCt1 = np.mean(p, axis=1).T, (np.std(p, axis=1) / (np.sqrt(6) - 1.0)).T
+    Cr, dCr = o.calculate_Ct_Palmer(v4)
+    assert np.max(np.abs(Ct1 - Cr)) < 1e-14 and np.max(np.abs(dCt1 - dCr)) < 1e-14          # and it IS the reference's C(t)
+    for rank, r0, nR, Ct, dCt in res:
+        assert np.array_equal(Ct, Ct1) and np.array_equal(dCt, dCt1), rank

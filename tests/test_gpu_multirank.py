@@ -83,3 +83,35 @@ def test_scripts_under_torchrun_write_the_single_process_files(tmp_path, synth_c
     import glob
     import tempfile
     assert not glob.glob(os.path.join(tempfile.gettempdir(), 'spinrelax_rank*'))
+
+
+def test_more_ranks_than_vectors_shards_the_replicate_chunks(tmp_path, synth_cache):
+    """V = 3 vectors on 4 ranks: C(t) is sharded over the replicate chunks (every rank all vectors of its chunk range), the
+    raw sums are gathered and the chunk-statistics kernel runs on all of them; the histogram / mean vector / S2 keep the
+    vector sharding (one rank idles).  The files must be byte-identical to a single process's -- dC(t) included, which an
+    all-reduce of sums and squares would round differently.  Two input files with tails, lab-frame vectors of their own."""
+    s = synth.config_shapes(1)
+    F = int(s['tau_memory'] / s['dt'])
+    fns = []
+    for k, (n, seed) in enumerate(((4 * F + 37, 51), (3 * F + 90, 52))):
+        fn = str(tmp_path / ('part%d.npz' % k))
+        np.savez(fn, vecs=synth.synth_vectors(n, 3, seed=seed), vecs_lab=synth.synth_vectors(n, 3, seed=seed + 10), names=np.array([7, 8, 11]), dt=s['dt'])
+        fns.append(fn)
+    quat = ' '.join('%.6f' % x for x in synth.Q_EXT)
+    outs = {}
+    for nproc in (1, 4):
+        d = str(tmp_path / ('n%d' % nproc))
+        os.makedirs(d)
+        out = os.path.join(d, 'rotdif')
+        run('calculate-Ct-from-traj.py', ['-s', 'ref.pdb', '-f'] + fns + ['--tau', s['tau_memory'], '-o', out, '--vecRot', quat, '--vecHist', '--binary',
+                                                                     '--vecAvg', '--S2', '--Ct'], nproc)
+        outs[nproc] = d
+    files = sorted(os.listdir(outs[1]))
+    assert files == sorted(os.listdir(outs[4])) and len(files) == 5
+    for f in files:
+        if f.endswith('.npz'):
+            a, b = np.load(os.path.join(outs[1], f), allow_pickle=True), np.load(os.path.join(outs[4], f), allow_pickle=True)
+            assert np.array_equal(a['data'], b['data']) and np.array_equal(a['names'], b['names'])
+        else:
+            assert filecmp.cmp(os.path.join(outs[1], f), os.path.join(outs[4], f), shallow=False), f
+    assert open(os.path.join(outs[1], 'rotdif_Ctext.dat')).read() != open(os.path.join(outs[1], 'rotdif_Ctint.dat')).read()

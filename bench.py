@@ -250,6 +250,10 @@ def cli_wall(vecs_host, s, cfg, cpu):
     return out
 
 
+def use_rfft_bench(args, s):
+    return args.ct_fft in (-1, 2) and 4096 < s['F'] + s['L'] <= 8192
+
+
 def fft_exec_flop(s, V, real_input=False):
     """executed float64 work per launch (formula; the committed PMC pass replaces it when it has the kernel).
     k_ct_fft: 4 complex M-point transforms (5 M log2 M flop each), the power spectra of 3 packed pairs (12 flop per
@@ -466,6 +470,16 @@ def main():
             ctx.set_option('ct_fft', 2 if args.ct_fft < 0 else args.ct_fft)
             with torch.cuda.stream(st1):
                 p1.stage_ct(s0)                 # restore the slot's sums / C(t) from the production kernel
+        # the other real-input FFT variant (M = 8192: 4096 < F <= 5461) on the same planes, at two chunk lengths: its cost per
+        # frame against the benchmark variant's
+        if use_rfft_bench(args, s):
+            per_frame = alone['ct'] / (s['R'] * s['F'])
+            for F2 in (5000, 5461):
+                R2 = s['frames'] // F2
+                ps2 = torch.empty((V * R2 * ctx.psum_stride(F2),), device=dev, dtype=torch.float64)
+                alone['ct_F%d' % F2] = timed(lambda: ctx.ct_sums_dev(p1.soa.data_ptr(), p1.Npad, R2, F2, V, ps2.data_ptr()), reps=2)
+                alone['ct_F%d_per_frame_vs_cfg3' % F2] = alone['ct_F%d' % F2] / (R2 * F2) / per_frame
+                del ps2
         # The model-order search with the chip saturated: 32 batches' residues in ONE launch, the expensive residues first
         # (sorted by the evaluations they needed in the batch above).  A lone launch lasts as long as its slowest residue
         # (~10 ms for one 286-evaluation fit); with several batches in flight that tail overlaps the next batches' work,

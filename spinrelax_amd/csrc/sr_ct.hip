@@ -946,6 +946,11 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
     cplx *lds = reinterpret_cast<cplx *>(fft_smem);
     constexpr int H = N1 * 256, M = 2 * H;
     constexpr int NZ = HALF ? (N1 == 12 ? 8 : N1 / 2) : N1;
+    // PF: the samples of signal c + 1 are loaded one transform ahead (2 NZ float2 registers held across the transform).  With
+    // all 16 input blocks in use that is 64 VGPRs the 256-register budget does not have (188 B of scratch, reloaded inside the
+    // transform): the M = 8192 kernel loads them right before it forms the signal and leaves the latency to the other
+    // workgroup of the CU.
+    constexpr bool PF = NZ <= 8;
     float *Pl = reinterpret_cast<float *>(lds + rfft_lds_slots(N1) + 512);     // TR: the trace term's table (2049 doubles), then scan scratch
     const int tid0 = threadIdx.x;
     const int v = blockIdx.x / a.R, r = blockIdx.x - v * a.R;
@@ -1104,7 +1109,7 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
 #pragma unroll
         for (int n1 = 0; n1 < NZ; ++n1)
             sig[n1] = cplx{(double)ar[n1].x * (double)br[n1].x, (double)ar[n1].y * (double)br[n1].y};
-        SR_RFFT_LOAD(1, tid0)
+        if (PF) SR_RFFT_LOAD(1, tid0)
     }
 #pragma unroll 1
     for (int c = 0; c < nsig; ++c) {
@@ -1158,6 +1163,7 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
         // assignment would keep the transform's in-place leftovers in `sig` alive through the spectrum step.
         {
             const int cn = c + 1;
+            if (!PF && cn < nsig) SR_RFFT_LOAD(cn, tid)
             // keep these products HERE: nothing ties them to this point but their inputs, and scheduled above the spectrum
             // step (where w[16] is live) they push the accumulators into scratch
 #pragma unroll
@@ -1188,7 +1194,7 @@ __global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
                     const double z0 = (double)ar[n1].x, z1 = (double)ar[n1].y;
                     sig[n1] = cplx{fma(z0, z0, sig[n1].re), fma(z1, z1, sig[n1].im)};
                 }
-            } else if (c + 2 < nsig) {
+            } else if (PF && c + 2 < nsig) {
                 SR_RFFT_LOAD(c + 2, tid)
             }
         }

@@ -515,9 +515,10 @@ extern __shared__ __align__(16) double fit_smem[];
 constexpr int kRedStride = kNmax * (kNmax + 1) / 2 + kNmax + 2;   // doubles per wave in the reduction scratch
 constexpr int kBcast = 16;
 constexpr int kMat = kNmax * (kNmax + 1) / 2;                        // one packed symmetric n x n matrix
+constexpr int kStateDoubles = 16;                                    // SearchState of k_order_search (workgroup-uniform)
 __host__ __device__ constexpr size_t fit_lds_doubles(int W, int64_t L_staged)
 {
-    return (size_t)W * kRedStride + kBcast + (2 + W) * kMat + 3 * (size_t)L_staged;
+    return (size_t)W * kRedStride + kBcast + (2 + W) * kMat + kStateDoubles + 3 * (size_t)L_staged;
 }
 
 template <int W, bool LDS>
@@ -528,7 +529,8 @@ struct Residue {
     static constexpr int MA = BC + kBcast;             // J^T J of the current point (packed), shared by all threads
     static constexpr int MB = MA + kMat;               // the scaled trust-region matrix B
     static constexpr int LF = MB + kMat;               // one Cholesky factor per wave (every lane writes the same values)
-    static constexpr int RED = LF + W * kMat;          // start of the staged residue
+    static constexpr int ST = LF + W * kMat;           // the model-order search's state (uniform; every thread writes the same values)
+    static constexpr int RED = ST + kStateDoubles;     // start of the staged residue
 
     const double *tg, *yg, *wg;   // global (LDS == false)
     const double *sg;             // sigma of this residue (global) or null
@@ -742,7 +744,10 @@ struct SolveParams {
 
 // curve_fit(...) of conduct_curve_fitting for the staged residue T, starting from p0 (registers).
 // Outputs: x (optimum), pc (packed covariance, valid when cov_ok), chi (calc_chiSq), status, nfev.
-template <int N, class R>
+// DIAG: pc receives only the N diagonal elements of the covariance (what the model-order search needs for its dP > P
+// test) -- computed by the same column solves as the full matrix, so the values are bit-identical; it just does not keep
+// 36 doubles per lane that nobody reads (they were a third of search_order<9>'s scratch frame).
+template <int N, bool DIAG, class R>
 __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const SolveParams &P, double *x, double *pc,
                                           bool &cov_ok, double &chi, int &status, int &nfev)
 {
@@ -917,8 +922,12 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
                 for (int i = 0; i < N; ++i) e[i] = (i == c) ? 1.0 : 0.0;
                 fwdN<N>(Lf, inv, e, z);
                 bwdN<N>(Lf, inv, z, col);
+                if (DIAG) {
+                    pc[c] = col[c] * s_sq;
+                } else {
 #pragma unroll
-                for (int i = c; i < N; ++i) pc[tri(i, c)] = col[i] * s_sq;
+                    for (int i = c; i < N; ++i) pc[tri(i, c)] = col[i] * s_sq;
+                }
             }
         }
     }
@@ -956,7 +965,7 @@ __global__ __launch_bounds__(W * 64) void k_trf(FitArgs a)
     for (int i = 0; i < N; ++i) p0[i] = a.p0[(int64_t)res * N + i];
     SolveParams P;
     P.tau_max = a.tau_max; P.ftol = a.ftol; P.xtol = a.xtol; P.gtol = a.gtol; P.max_nfev = a.max_nfev; P.jac_mode = a.jac_mode;
-    trf_solve<N>(T, p0, P, x, pc, cov_ok, chi, status, nfev);
+    trf_solve<N, false>(T, p0, P, x, pc, cov_ok, chi, status, nfev);
     if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < N; ++i) a.popt[(int64_t)res * N + i] = x[i];
@@ -1036,7 +1045,11 @@ __device__ __noinline__ void search_order(const R T, const SearchArgs &a, int j,
 {
     constexpr int K = N / 2;
     constexpr bool kFree = (N % 2) == 1;
-    constexpr int NT = N * (N + 1) / 2;
+    // the state as the previous order left it, read BEFORE the solve: st lives in LDS and every wave updates it at the end of
+    // an order, so a wave that reaches the accept / reject step late must not see what an earlier wave has already written
+    // for THIS order (the solve's barriers keep the waves less than one order apart)
+    const bool st_first = st.first;
+    const double st_best_chi = st.best_chi;
     double p0[N], c0, sumC, S2_0;
     {
 #pragma clang fp contract(off)
@@ -1054,10 +1067,10 @@ __device__ __noinline__ void search_order(const R T, const SearchArgs &a, int j,
 
     SolveParams P;
     P.tau_max = a.tau_max; P.ftol = a.ftol; P.xtol = a.xtol; P.gtol = a.gtol; P.max_nfev = 100 * N; P.jac_mode = 0;
-    double x[N], pc[NT], chi;
+    double x[N], pc[N], chi;
     bool cov_ok;
     int status, nfev;
-    trf_solve<N>(T, p0, P, x, pc, cov_ok, chi, status, nfev);
+    trf_solve<N, true>(T, p0, P, x, pc, cov_ok, chi, status, nfev);
 
     // quality flags, fitting_Ct_functions.py:320-338 (the sum > 1 test runs on the INITIAL guess: reference quirk)
     const bool ok = status > 0;
@@ -1065,7 +1078,7 @@ __device__ __noinline__ void search_order(const R T, const SearchArgs &a, int j,
     double dP[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        dP[i] = cov_ok ? sqrt(pc[tri(i, i)]) : INFINITY;
+        dP[i] = cov_ok ? sqrt(pc[i]) : INFINITY;
         if (dP[i] > x[i]) q1 = false;
     }
     bool q2;
@@ -1089,10 +1102,10 @@ __device__ __noinline__ void search_order(const R T, const SearchArgs &a, int j,
     }
     // accept / reject, optimised_curve_fitting :278-304
     bool take = false;
-    if (st.first) {
+    if (st_first) {
         if (allq) { take = true; st.first = false; }
     } else {
-        if (!allq || chiSq >= st.best_chi * a.chi_thr) st.done = true;
+        if (!allq || chiSq >= st_best_chi * a.chi_thr) st.done = true;
         else take = true;
     }
     if (take) {
@@ -1130,7 +1143,11 @@ __global__ __launch_bounds__(W * 64, SR_FIT_WAVES_EU) void k_order_search(Search
             a.nfev[o] = 0;
         }
     }
-    SearchState st;
+    // The search state lives in LDS, not on the stack: it crosses the (non-inlined) per-order solver calls by reference, and a
+    // stack object costs every lane a scratch frame.  It is workgroup-uniform: every thread stores the same values and reads
+    // them back behind its own stores (LDS operations of a wave complete in order), so no barrier is needed.
+    static_assert(sizeof(SearchState) <= kStateDoubles * sizeof(double), "SearchState does not fit its LDS slot");
+    SearchState &st = *reinterpret_cast<SearchState *>(fit_smem + Residue<W, LDS>::ST);
     st.first = true; st.done = false; st.best = -1; st.best_chi = INFINITY;
 #pragma unroll
     for (int i = 0; i < kNmax; ++i) st.xbest[i] = 0.0;

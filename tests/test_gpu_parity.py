@@ -441,41 +441,57 @@ def test_resjac_vs_oracle_and_reference_chi(ctx):
 def test_device_fit_vs_reference_trials(ctx, tag):
     """Every (residue, model order) trial of the fixtures, started from the reference's own p0.
 
-    The device solver restates scipy's TRF step for step (sr_fit.hip) and normally needs exactly the
-    same number of function evaluations.  What limits agreement is the reference itself: scipy's result
-    moves by 1e-7 .. 3e-5 in chi^2 (and sometimes in nfev) when exp() changes by one ulp
-    (DESIGN.md "fit parity", measured with the real scipy), because ftol = xtol = 1e-8 stop a run
-    ~1e-4 from the stationary point along flat directions.  Hence the tiers:
-      (i)  chi^2 at the reference's optimum: 1e-9 (test_resjac_vs_oracle_and_reference_chi);
-      (ii) fitted chi^2 within 1e-4 for the well-conditioned orders (<= 5 parameters), failures of the
-           reference reproduced exactly (same residues fail for the same reason);
-      (iii) over-parameterised orders (7, 9 parameters; the reference flags most of them as
-           over-fitted) are only required to reach a comparable minimum."""
+    The device solver restates scipy's TRF step for step (sr_fit.hip) and normally needs exactly the same number of
+    function evaluations.  The bar is per trial:  |chi^2 / chi^2_ref - 1| <= 1e-6 for orders of up to 5 parameters and
+    <= 1e-4 for the over-parameterised 7 / 9-parameter orders -- unless the REFERENCE ITSELF does not pin its answer that
+    well: tests/golden/<tag>_fit_sens.npz (oracle/gen_golden_fit_sensitivity.py) holds, for every trial, the chi^2 values
+    the real reference reaches when its input C(t) changes by ONE ulp (64 / 32 / 16 perturbed runs per trial; the size of
+    change a different exp() or summation order makes).  ftol = xtol = 1e-8 stop a TRF run ~1e-4 from the stationary point
+    along flat directions, so at L = 50 (cfg1) the reference's own 9-parameter chi^2 moves by up to 150 %, its 7-parameter
+    fit of residue 26 jumps to a minimum 24 % higher in 2 of 64 runs (the one the device lands in), and even its
+    2-parameter fits move by 1.7e-6; at L >= 512 everything up to 7 parameters is stable to 2e-5 or better.
+      * every trial the reference pins ten times better than the tier must meet the tier;
+      * any other trial must meet the tier, OR lie inside the reference's own range of outcomes (widened by half its width),
+        OR deviate by no more than three times the reference's own largest deviation: the perturbed runs sample what the
+        reference does under one-ulp changes, they do not bound it.
+    Failures of the reference are reproduced (same residues fail)."""
     g = golden('%s_fit.npz' % tag)
+    sens = golden('%s_fit_sens.npz' % tag)
     t, y, dy = g['t'], g['y'], g['dy']
     nres = y.shape[0]
     tau_max = t[0, -1] * 10
-    lo_tot = lo_ok = hi_tot = hi_ok = 0
+    stats = {}
     for j, nP in enumerate(g['listDoG']):
         p0 = g['trial_p0'][:, j, :nP]
         popt, pcov, chi, status, nfev = ctx.expfit(t, y, dy, p0, tau_max)
         K = nP // 2
+        tier = 1e-6 if nP <= 5 else 1e-4
+        n = within = pinned = over = 0
+        worst = 0.0
         for i in range(nres):
             ref_ok = bool(g['trial_quality'][i, j, 0])
-            assert (status[i] > 0) == ref_ok or nP >= 7
+            assert (status[i] > 0) == ref_ok or nP >= 7 or bool(sens['trial_ok_flip'][i, j])
             if not ref_ok or status[i] <= 0:
                 continue
             rel = abs(chi[i] / g['trial_chi'][i, j] - 1)
+            spread = float(sens['trial_chi_spread'][i, j])
             assert np.all(popt[i, :K] >= 0) and np.all(popt[i, :K] <= 1) and np.all(popt[i, K:2 * K] <= tau_max)
-            if nP <= 5:
-                lo_tot += 1
-                lo_ok += rel < 1e-4
-            else:
-                hi_tot += 1
-                hi_ok += rel < 5e-2
-    print('%s: <=5 params %d/%d within 1e-4;  7-9 params %d/%d within 5e-2' % (tag, lo_ok, lo_tot, hi_ok, hi_tot))
-    assert lo_ok >= 0.97 * lo_tot
-    assert hi_ok >= 0.85 * hi_tot
+            n += 1
+            within += rel <= tier
+            if spread <= 0.1 * tier:
+                pinned += 1
+                assert rel <= tier, (tag, nP, i, rel, spread)                 # the reference pins it: so must the device
+            elif rel > tier:
+                over += 1
+                lo, hi = float(sens['trial_chi_lo'][i, j]), float(sens['trial_chi_hi'][i, j])
+                inside = lo * (1 - tier) - 0.5 * (hi - lo) <= chi[i] <= hi * (1 + tier) + 0.5 * (hi - lo)
+                assert inside or rel <= 3.0 * spread, (tag, nP, i, rel, spread, chi[i], lo, hi)
+            worst = max(worst, rel)
+        stats[int(nP)] = (n, within, pinned, over, worst)
+    print('\n[fit trials %s] order: fits, within tier, pinned by the reference (all within tier), beyond tier where the reference itself moves, worst'
+          % tag)
+    for nP, (n, within, pinned, over, worst) in stats.items():
+        print('   %d parameters: %3d, %3d, %3d, %3d, %.1e' % (nP, n, within, pinned, over, worst))
 
 
 def test_device_fit_failure_modes(ctx):

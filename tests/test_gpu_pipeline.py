@@ -236,7 +236,8 @@ def test_bench_json_contract():
     if r['frac'] is not None:
         assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0 < r['frac'] <= 1
     ct = ks['k_ct_rfft']
-    assert 0 < ct['in_pipeline_ms'] < j['ms_per_step'] * 1.05 and ct['alone_ms'] <= ct['in_pipeline_ms'] * 1.05
+    # (two C(t) launches of consecutive batches overlap each other and the fits: a launch LASTS longer than a step)
+    assert 0 < ct['in_pipeline_ms'] < j['ms_per_step'] * 3 and ct['alone_ms'] <= ct['in_pipeline_ms'] * 1.05
     assert abs(ct['frac'] - ct['work_per_launch'] / (ct['in_pipeline_ms'] * 1e-3) / 1e12 / ct['peak']) < 1e-9
     assert ct['work_per_launch'] < 0.1 * 8 * j['config']['exact_triples_per_gpu']          # the FFT formulation executes < 10 % of the direct flop
     vh = ks['k_vechist']

@@ -346,6 +346,10 @@ int sr_xh_vectors_f32(sr_ctx *, const float *xyz, int64_t nFrames, int64_t nAtom
  *          are the sums over the chunks.  Products and sums in float64 on the float32 input. */
 int sr_dq_moments_f32_dev(sr_ctx *, const float *q, int64_t N, const int32_t *lags_host, int nlags, int nchunk, double *out);
 int sr_dq_moments_f32(sr_ctx *, const float *q, int64_t N, const int32_t *lags, int nlags, int nchunk, double *out);
+/* the same on float64 quaternions: the reference's gmx-rotmat route (rotmatrix_to_quaternion, calculate-dq-distribution.py:
+ * 482-497) keeps float64, and its short-lag moments (|v| ~ 1e-2) would lose five digits in a float32 round trip */
+int sr_dq_moments_f64_dev(sr_ctx *, const double *q, int64_t N, const int32_t *lags_host, int nlags, int nchunk, double *out);
+int sr_dq_moments_f64(sr_ctx *, const double *q, int64_t N, const int32_t *lags, int nlags, int nchunk, double *out);
 
 /* ---- small device utilities ---------------------------------------------------------------
  * out[c*rows + r] = in[r*cols + c] (float64, device pointers): C(t) leaves kernel 1 as (lags, vectors)

@@ -135,8 +135,33 @@ def main():
     import plumedcolvario as ref_pl
     names, data = quiet(ref_pl.read_from_plumedprint, os.path.join(GOLD, 'cfg1_colvar-qorient'))
     run_case('dqB', np.ascontiguousarray(data[1:5].T), float(data[0, 1] - data[0, 0]), 1, 40, 1, 3)
+    # (c) float64 quaternions (what the reference's gmx-rotmat route holds: rotmatrix_to_quaternion keeps float64,
+    #     calculate-dq-distribution.py:406-423, 482-497): the synthetic walk nudged off the float32 grid and re-normalised in
+    #     float64; only the per-lag reductions are stored (obtain_self_dq / tensor / average_LegendreP1quat[_chunk])
+    q64 = synth.synth_orientation(5000, 12).astype(np.float64)
+    q64 += 1e-9 * np.sin(np.arange(q64.size, dtype=np.float64)).reshape(q64.shape)
+    q64 /= np.sqrt((q64 * q64).sum(axis=1))[:, None]
+    assert not np.array_equal(q64, q64.astype(np.float32).astype(np.float64))
+    lags = list(range(1, 40, 3))
+    nch = 3
+    iso = np.zeros(len(lags))
+    moi = np.zeros((len(lags), 3, 3))
+    ch_iso = np.zeros((nch, len(lags)))
+    ch_moi = np.zeros((nch, len(lags), 3, 3))
+    for k, d in enumerate(lags):
+        vq = rdq.obtain_self_dq(q64, d)[..., 1:4]
+        nd = vq.shape[0]
+        iso[k] = rdq.average_LegendreP1quat(nd, vq)
+        moi[k] = tensor(vq)
+        ch_iso[:, k] = rdq.average_LegendreP1quat_chunk(nd, vq, nch)
+        for c, (a, b) in enumerate(chunks(nd, nch)):
+            ch_moi[c, k] = tensor(vq[a:b])
+    np.savez_compressed(os.path.join(GOLD, 'dqC_dq.npz'), q64=q64, lags=np.array(lags), num_chunk=nch, iso=iso, moi=moi,
+                        chunk_iso=ch_iso, chunk_moi=ch_moi)
+    print('wrote dqC_dq.npz (float64 quaternions)')
     mf = os.path.join(GOLD, 'MANIFEST.json')
     man = json.load(open(mf))
+    man['dqC_dq.npz'] = 'reference reductions of calculate-dq-distribution.py on FLOAT64 quaternions (oracle/gen_golden_dq.py, case c)'
     for tag in ('dqA', 'dqB'):
         man['%s_dq.npz' % tag] = 'reference reductions of calculate-dq-distribution.py (oracle/gen_golden_dq.py)'
     with open(mf, 'w') as fp:

@@ -82,6 +82,8 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p]),
     'sr_dq_moments_f32_dev': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p]),
     'sr_dq_moments_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p]),
+    'sr_dq_moments_f64_dev': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p]),
+    'sr_dq_moments_f64': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p]),
     # (ctx, E, nRes, stats, column, csa_prefactor, noe_factor, f_DD, target, dtarget, cover, has_err, csa0, step, xtol, ftol,
     #  csa, values, errors, fopt, nfev)
     'sr_rscsa_search_f64': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -1292,6 +1292,7 @@ int launch_ct_rfft(sr_ctx *ctx, const CtRfftArgs &a, int64_t series)
 // the (lags, vectors) arrays with a stride of nV doubles: 445 MB of HBM traffic for 218 MB of data, and two transposition
 // launches behind it.)
 constexpr int kFinV = 16, kFinD = 64;
+constexpr int kFinR = 32;          // replicate chunks a thread keeps in registers (more: two passes over memory)
 __global__ __launch_bounds__(256) void k_ct_finalize(const double *__restrict__ psum, int R, int F, int L, int Lp,
                                                      int64_t nV, double *__restrict__ Ct, double *__restrict__ dCt,
                                                      double *__restrict__ CtT, double *__restrict__ dCtT)
@@ -1311,13 +1312,31 @@ __global__ __launch_bounds__(256) void k_ct_finalize(const double *__restrict__ 
             if (d > L || v >= nV) continue;
             const double *p = psum + v * R * Lp + d;
             const double n = (double)(F - d);
-            double m = 0.0;
-            for (int r = 0; r < R; ++r) m += 1.5 * (p[(int64_t)r * Lp] / n) - 0.5;
-            m /= (double)R;
-            double s = 0.0;
-            for (int r = 0; r < R; ++r) {
-                const double e = (1.5 * (p[(int64_t)r * Lp] / n) - 0.5) - m;
-                s += e * e;
+            double m = 0.0, s = 0.0;
+            if (R <= kFinR) {
+                // the replicate values stay in registers between the two passes of numpy.std: the raw sums (201 MB for cfg3)
+                // are read once, all loads in flight together
+                double pr[kFinR];
+#pragma unroll
+                for (int r = 0; r < kFinR; ++r) pr[r] = r < R ? p[(int64_t)r * Lp] : 0.0;
+#pragma unroll
+                for (int r = 0; r < kFinR; ++r) {
+                    pr[r] = 1.5 * (pr[r] / n) - 0.5;
+                    if (r < R) m += pr[r];
+                }
+                m /= (double)R;
+#pragma unroll
+                for (int r = 0; r < kFinR; ++r) {
+                    const double e = pr[r] - m;
+                    if (r < R) s += e * e;
+                }
+            } else {
+                for (int r = 0; r < R; ++r) m += 1.5 * (p[(int64_t)r * Lp] / n) - 0.5;
+                m /= (double)R;
+                for (int r = 0; r < R; ++r) {
+                    const double e = (1.5 * (p[(int64_t)r * Lp] / n) - 0.5) - m;
+                    s += e * e;
+                }
             }
             const double sd = sqrt(s / (double)R) / rootR;
             tm[vl][dl] = m;

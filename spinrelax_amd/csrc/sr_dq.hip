@@ -26,13 +26,16 @@
 namespace {
 
 struct DqArgs {
-    const float4 *q;        // (N) quaternions w, x, y, z
+    const void *q;          // (N) quaternions w, x, y, z: float4, or 4 doubles each (the F64 kernel)
     int64_t N;
     const int *lags;        // (nlags) device
     int nlags, nchunk, nsub;
     double *partials;       // (nlags, nchunk, nsub, 6)
 };
 
+// F64: float64 quaternions in (the gmx rotmat .xvg route of the reference keeps float64: rotmatrix_to_quaternion,
+// calculate-dq-distribution.py:482-497); same arithmetic, the conversions drop out
+template <bool F64>
 __global__ __launch_bounds__(256) void k_dq_moments(DqArgs a)
 {
 #pragma clang fp contract(off)
@@ -53,11 +56,20 @@ __global__ __launch_bounds__(256) void k_dq_moments(DqArgs a)
             int64_t hi = lo + per;
             if (hi > jmax) hi = jmax;
             for (int64_t i = lo + tid; i < hi; i += 256) {
-                const float4 A = a.q[i], B = a.q[i + d];
+                double w1, x1, y1, z1, w2, x2, y2, z2;
                 // q1 = quat_invert(q_i) = (w, -x, -y, -z); out = quat_mult_simd(q1, q2), vector part only:
                 //   w1 v2 + w2 v1 + v1 x v2      (transforms3d_supplement.py:182)
-                const double w1 = (double)A.x, x1 = -(double)A.y, y1 = -(double)A.z, z1 = -(double)A.w;
-                const double w2 = (double)B.x, x2 = (double)B.y, y2 = (double)B.z, z2 = (double)B.w;
+                if (F64) {
+                    const double2 *qd = reinterpret_cast<const double2 *>(a.q);
+                    const double2 A0 = qd[2 * i], A1 = qd[2 * i + 1], B0 = qd[2 * (i + d)], B1 = qd[2 * (i + d) + 1];
+                    w1 = A0.x; x1 = -A0.y; y1 = -A1.x; z1 = -A1.y;
+                    w2 = B0.x; x2 = B0.y; y2 = B1.x; z2 = B1.y;
+                } else {
+                    const float4 *qf = reinterpret_cast<const float4 *>(a.q);
+                    const float4 A = qf[i], B = qf[i + d];
+                    w1 = (double)A.x; x1 = -(double)A.y; y1 = -(double)A.z; z1 = -(double)A.w;
+                    w2 = (double)B.x; x2 = (double)B.y; y2 = (double)B.z; z2 = (double)B.w;
+                }
                 const double vx = (w1 * x2 + w2 * x1) + (y1 * z2 - z1 * y2);
                 const double vy = (w1 * y2 + w2 * y1) + (z1 * x2 - x1 * z2);
                 const double vz = (w1 * z2 + w2 * z1) + (x1 * y2 - y1 * x2);
@@ -112,16 +124,15 @@ __global__ __launch_bounds__(64) void k_dq_finalize(const double *__restrict__ p
 
 extern "C" {
 
-int sr_dq_moments_f32_dev(sr_ctx *ctx, const float *q, int64_t N, const int32_t *lags_host, int nlags, int nchunk,
-                          double *out)
+static int dq_moments_dev(sr_ctx *ctx, const void *q, bool f64, int64_t N, const int32_t *lags_host, int nlags, int nchunk, double *out)
 {
     SR_CHECK_CTX(ctx);
-    SR_REQUIRE(q && lags_host && out, -2, "sr_dq_moments_f32_dev: null pointer");
+    SR_REQUIRE(q && lags_host && out, -2, "sr_dq_moments_dev: null pointer");
     SR_REQUIRE(N >= 2 && nlags >= 1 && nchunk >= 1 && nchunk <= 65535 && nlags <= 65535, -3,
-               "sr_dq_moments_f32_dev: bad sizes N=%lld nlags=%d nchunk=%d", (long long)N, nlags, nchunk);
+               "sr_dq_moments_dev: bad sizes N=%lld nlags=%d nchunk=%d", (long long)N, nlags, nchunk);
     int64_t dmin = N;
     for (int k = 0; k < nlags; ++k) {
-        SR_REQUIRE(lags_host[k] >= 1 && lags_host[k] < N, -3, "sr_dq_moments_f32_dev: lag %d = %d out of range (1..%lld)", k,
+        SR_REQUIRE(lags_host[k] >= 1 && lags_host[k] < N, -3, "sr_dq_moments_dev: lag %d = %d out of range (1..%lld)", k,
                    lags_host[k], (long long)(N - 1));
         if (lags_host[k] < dmin) dmin = lags_host[k];
     }
@@ -138,14 +149,42 @@ int sr_dq_moments_f32_dev(sr_ctx *ctx, const float *q, int64_t N, const int32_t 
     SR_HIP(hipMemcpyAsync(lags_d, lags_host, (size_t)nlags * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     SR_HIP(hipStreamSynchronize(ctx->stream));
     DqArgs a;
-    a.q = reinterpret_cast<const float4 *>(q); a.N = N; a.lags = lags_d; a.nlags = nlags; a.nchunk = nchunk;
+    a.q = q; a.N = N; a.lags = lags_d; a.nlags = nlags; a.nchunk = nchunk;
     a.nsub = (int)nsub; a.partials = partials;
-    hipLaunchKernelGGL(k_dq_moments, dim3((unsigned)nsub, (unsigned)nchunk, (unsigned)nlags), dim3(256), 0, ctx->stream, a);
+    if (f64) hipLaunchKernelGGL(k_dq_moments<true>, dim3((unsigned)nsub, (unsigned)nchunk, (unsigned)nlags), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_dq_moments<false>, dim3((unsigned)nsub, (unsigned)nchunk, (unsigned)nlags), dim3(256), 0, ctx->stream, a);
     SR_HIP(hipGetLastError());
     const int tot = nlags * nchunk * 7;
     hipLaunchKernelGGL(k_dq_finalize, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, ctx->stream, partials, lags_d, N, nlags,
                        nchunk, (int)nsub, out);
     SR_HIP(hipGetLastError());
+    return 0;
+}
+
+int sr_dq_moments_f32_dev(sr_ctx *ctx, const float *q, int64_t N, const int32_t *lags_host, int nlags, int nchunk, double *out)
+{
+    return dq_moments_dev(ctx, q, false, N, lags_host, nlags, nchunk, out);
+}
+
+int sr_dq_moments_f64_dev(sr_ctx *ctx, const double *q, int64_t N, const int32_t *lags_host, int nlags, int nchunk, double *out)
+{
+    return dq_moments_dev(ctx, q, true, N, lags_host, nlags, nchunk, out);
+}
+
+int sr_dq_moments_f64(sr_ctx *ctx, const double *q, int64_t N, const int32_t *lags, int nlags, int nchunk, double *out)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(q && lags && out, -2, "sr_dq_moments_f64: null pointer");
+    SR_REQUIRE(N >= 2 && nlags >= 1 && nchunk >= 1, -3, "sr_dq_moments_f64: bad sizes");
+    const size_t nout = (size_t)nlags * nchunk * 7;
+    double *q_d = (double *)sr_workspace(ctx, SR_WS_VECS, (size_t)N * 4 * sizeof(double));
+    double *out_d = (double *)sr_workspace(ctx, SR_WS_OUT0, nout * sizeof(double));
+    if (!q_d || !out_d) return -5;
+    SR_HIP(hipMemcpyAsync(q_d, q, (size_t)N * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int rc = sr_dq_moments_f64_dev(ctx, q_d, N, lags, nlags, nchunk, out_d);
+    if (rc) return rc;
+    SR_HIP(hipMemcpyAsync(out, out_d, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

@@ -58,7 +58,8 @@ def calculate_anisotropies(D, chunkD=[]):
 # ---- device reductions -------------------------------------------------------------------------------------------
 def dq_moments(q, lags, nchunk=1, ctx=None):
     """(nlags, nchunk, 7) float64 from the GPU: sums of xx yy zz xy xz yz of vec(q_i^-1 q_{i+lag}) and the count."""
-    return _ctx(ctx).dq_moments(np.ascontiguousarray(q, dtype=np.float32), lags, nchunk)
+    q = np.asarray(q)
+    return _ctx(ctx).dq_moments(np.ascontiguousarray(q, dtype=np.float64 if q.dtype == np.float64 else np.float32), lags, nchunk)
 
 
 def moments_to_tensor(m):
@@ -270,7 +271,8 @@ def analyse(data, min_dt=0.0, max_dt=1000.0, skip_dt=0.0, num_chunk=0, bDoIso=Tr
     bDoSubchunk = num_chunk > 1
     lags = list(range(min_int, max_int + 1, skip_int))
     tot_int = len(lags)
-    q32 = np.ascontiguousarray(data[1:5].T, dtype=np.float32)
+    # float32 from the PLUMED reader (plumedcolvario.py:14-15), float64 from the gmx-rotmat route: each keeps its precision
+    q32 = np.ascontiguousarray(data[1:5].T, dtype=np.float64 if data.dtype == np.float64 else np.float32)
     nch = num_chunk if bDoSubchunk else 1
     mom = dq_moments(q32, lags, nch, ctx=ctx)                  # ONE launch: (tot_int, nch, 7)
     total = mom.sum(axis=1)

@@ -257,15 +257,18 @@ class Context:
 
     # ---- global rotational diffusion (calculate-dq-distribution.py) ----
     def dq_moments(self, q, lags, nchunk=1):
-        """q (N, 4) float32 (w x y z); lags: frame offsets -> (nlags, nchunk, 7) float64: sums of xx yy zz xy xz yz of the
-        vector part of q_i^-1 q_{i+lag} over every chunk's samples, and the sample count."""
-        q = _f32(q)
+        """q (N, 4) (w x y z), float32 (PLUMED's precision) or float64 (kept as float64: the gmx-rotmat route); lags: frame
+        offsets -> (nlags, nchunk, 7) float64: sums of xx yy zz xy xz yz of the vector part of q_i^-1 q_{i+lag} over every
+        chunk's samples, and the sample count."""
+        q = np.asarray(q)
+        f64 = q.dtype == np.float64
+        q = _f64(q) if f64 else _f32(q)
         if q.ndim != 2 or q.shape[1] != 4:
             raise ValueError('q must be (N, 4)')
         lg = np.ascontiguousarray(lags, dtype=np.int32)
         out = np.empty((lg.size, int(nchunk), 7))
-        check(self.lib.sr_dq_moments_f32(self.h, _ptr(q), q.shape[0], _ptr(lg), lg.size, int(nchunk), _ptr(out)),
-              'sr_dq_moments_f32')
+        fn = self.lib.sr_dq_moments_f64 if f64 else self.lib.sr_dq_moments_f32
+        check(fn(self.h, _ptr(q), q.shape[0], _ptr(lg), lg.size, int(nchunk), _ptr(out)), 'sr_dq_moments_f64' if f64 else 'sr_dq_moments_f32')
         return out
 
     # ---- residue-specific CSA search (new class API) ----

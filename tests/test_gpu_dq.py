@@ -35,6 +35,34 @@ def _q_of(tag, g):
     return q
 
 
+def test_dq_moments_float64_quaternions_keep_their_precision(ctx):
+    """The reference's gmx-rotmat route holds float64 quaternions (rotmatrix_to_quaternion, calculate-dq-distribution.py:
+    406-423) and reduces them in float64.  sr_dq_moments_f64 does the same: against the reference's reductions on float64
+    input (tests/golden/dqC_dq.npz) to 1e-12 -- while the same data pushed through float32 first is off by ~1e-5 at the
+    shortest lags (|v| ~ 1e-2: the deviation the advisor pointed at)."""
+    g = golden('dqC_dq.npz')
+    q64, lags, nch = g['q64'], g['lags'], int(g['num_chunk'])
+    assert q64.dtype == np.float64
+    m = ctx.dq_moments(q64, lags, nch)
+    tot = m.sum(axis=1)
+    scale = np.abs(g['moi']).max(axis=(1, 2))[:, None, None]
+    assert np.max(np.abs(dq.moments_to_tensor(tot) - g['moi']) / scale) < 1e-12
+    assert np.max(np.abs(np.moveaxis(dq.moments_to_tensor(m), 1, 0) - g['chunk_moi']) / scale[None]) < 1e-12
+    assert np.max(np.abs(dq.average_LegendreP1quat(tot) / g['iso'] - 1)) < 1e-12
+    assert np.max(np.abs(dq.average_LegendreP1quat(m).T / g['chunk_iso'] - 1)) < 1e-12
+    # analyse() keeps float64 data in float64 (time column + quaternions, as rotmatrix_to_quaternion returns them)
+    data = np.concatenate((np.arange(q64.shape[0], dtype=np.float64)[None] * 10.0, q64.T))
+    res = dq.analyse(data, min_dt=10.0, max_dt=380.0, skip_dt=30.0, num_chunk=nch, ctx=ctx)
+    direct = dq.average_LegendreP1quat(ctx.dq_moments(q64, res['lags'], 1).sum(axis=1))
+    assert len(res['lags']) >= 10 and np.max(np.abs(res['out_isolist'] / direct - 1)) < 1e-13
+    res32 = dq.analyse(data.astype(np.float32), min_dt=10.0, max_dt=380.0, skip_dt=30.0, num_chunk=nch, ctx=ctx)
+    assert np.max(np.abs(res32['out_isolist'] / direct - 1)) > 1e-9          # float32 data stay float32 (PLUMED's precision)
+    # the float32 round trip is visibly worse at short lags -- which is why the float64 entry point exists
+    m32 = ctx.dq_moments(q64.astype(np.float32), lags, nch).sum(axis=1)
+    err32 = np.abs(dq.moments_to_tensor(m32) - g['moi']) / scale
+    assert err32.max() > 1e-10          # (the fixture quaternions sit 1e-9 off the float32 grid)
+
+
 @pytest.mark.parametrize('tag', ['dqA', 'dqB'])
 def test_dq_moments_vs_reference_and_oracle(ctx, tag):
     g = golden('%s_dq.npz' % tag)

@@ -38,6 +38,30 @@ void *sr_workspace(sr_ctx *ctx, int slot, size_t bytes)
     return p;
 }
 
+int sr_grant_lds(sr_ctx *ctx, int kid, const void *func, size_t bytes)
+{
+    static int mu = 0;                         // spin lock (the table is touched a handful of times per process)
+    static size_t granted[64][8];              // [device][kernel family], largest size granted in this process
+    if (ctx->device < 0 || ctx->device >= 64 || kid < 0 || kid >= 8) {
+        hipError_t e_ = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e_ != hipSuccess) { sr_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) -> %s", bytes, hipGetErrorString(e_)); return -100 - (int)e_; }
+        return 0;
+    }
+    while (__atomic_exchange_n(&mu, 1, __ATOMIC_ACQUIRE)) {}
+    int rc = 0;
+    if (bytes > granted[ctx->device][kid]) {
+        hipError_t e_ = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e_ != hipSuccess) {
+            sr_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) -> %s", bytes, hipGetErrorString(e_));
+            rc = -100 - (int)e_;
+        } else {
+            granted[ctx->device][kid] = bytes;
+        }
+    }
+    __atomic_store_n(&mu, 0, __ATOMIC_RELEASE);
+    return rc;
+}
+
 extern "C" {
 
 int sr_abi_version(void) { return SR_ABI_VERSION; }

@@ -24,9 +24,6 @@ struct sr_ctx {
                         // (default), 1 = complex FFT formulation (k_ct_fft) everywhere, 0 = always the direct kernel
     int ct_traceless;   // 1: k_ct_rfft<12> in its traceless five-signal form (faster alone, slower inside the pipeline: default 0)
     int fft_table_ready;
-    // largest dynamic-LDS size already granted per kernel family (hipFuncSetAttribute is a per-DEVICE setting and a
-    // context is bound to one device, so the cache lives here and not in a process-wide static)
-    size_t lds_granted[8];
     // strided host -> device copies of bond vectors (sr_vectors.hip): two pinned staging buffers, and what went through them
     void *stage[2];
     hipEvent_t stage_ev[2];
@@ -77,18 +74,10 @@ static inline size_t sr_lds_limit(const sr_ctx *ctx)
     return a > b ? a : b;
 }
 
-// allow `func` to be launched with `bytes` of dynamic LDS on this context's device (no-op when already granted)
-static inline int sr_grant_lds(sr_ctx *ctx, int kid, const void *func, size_t bytes)
-{
-    if (bytes <= ctx->lds_granted[kid]) return 0;
-    hipError_t e_ = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e_ != hipSuccess) {
-        sr_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) -> %s", bytes, hipGetErrorString(e_));
-        return -100 - (int)e_;
-    }
-    ctx->lds_granted[kid] = bytes;
-    return 0;
-}
+// allow `func` to be launched with `bytes` of dynamic LDS on this context's device.  hipFuncSetAttribute is a per-DEVICE
+// function attribute: the largest size granted so far is remembered per (device, kernel family) for the whole PROCESS
+// (monotonic, under a mutex; sr_core.hip), so two contexts on one device can never lower each other's grant.
+int sr_grant_lds(sr_ctx *ctx, int kid, const void *func, size_t bytes);
 
 static inline int64_t sr_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 

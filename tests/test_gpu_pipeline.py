@@ -201,6 +201,31 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     assert j['fit']['residues'] == 64 and j['fit']['unfitted'] == 0
 
 
+def test_bench_single_rank_under_torchrun_equals_plain_run():
+    """The driver's SCALE run launches N = 1 the same way as N = 2, 4, 8 (torch.distributed.run) and compares it with the
+    plain `python bench.py` of BENCH: both must take the same code path -- same workload, same shard (rank 0 = vectors
+    0 .. V-1), the same fits evaluation for evaluation -- and agree in throughput to the box's run-to-run spread."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = ['--gpus', '1', '--steps', '8', '--warmup', '2', '--no-cpu-baseline', '--no-cli-wall', '--no-kernel-profile', '--spinup-s', '0.3',
+             '--steady-steps', '0', '--repeats', '3']
+    outs = []
+    for launcher in ([sys.executable], [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                                        '127.0.0.1', '--master-port', '29581']):
+        p = subprocess.run(launcher + [os.path.join(root, 'bench.py')] + flags, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+        assert len(lines) == 1
+        outs.append(json.loads(lines[0]))
+    a, b = outs
+    assert a['config'] == b['config'] and a['n_gpus'] == b['n_gpus'] == 1 and a['metric'] == b['metric'] and a['dtype'] == b['dtype']
+    assert a['fit'] == b['fit']                                   # same residues, same orders, same evaluation counts
+    assert abs(a['value'] / b['value'] - 1) < 0.15
+
+
 def test_bench_json_contract():
     """bench.py prints ONE JSON line with the agreed keys, the roofline object of the dominant kernel (measured live with
     events on its stream) and the CPU baseline timed beside it (a 1-vector sample here to keep the test short)."""

@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """
-Turn raw rocprofv3 output (under gpurun_out/) into the summaries committed under profiles/.
+Turn raw rocprofv3 output (under gpurun_out/<tag>prof/, collected by scripts/profile_round.sh) into the summaries committed
+under profiles/.
 
-    python scripts/make_profiles.py <round tag> <stats dir> <FETCH_SIZE dir> <WRITE_SIZE dir> [<FP64 instruction dir>]
+    python scripts/make_profiles.py <round tag> gpurun_out/<tag>prof
 
-  stats dir       rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python bench.py ...
-  FETCH/WRITE dir rocprofv3 --pmc FETCH_SIZE (resp. WRITE_SIZE) --kernel-trace --output-format csv -d <dir> -- python bench.py ...
-                  (separate passes, as MI355X_MICROARCH.md prescribes; never combined with other trace domains)
-  FP64 dir        rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64
-                  --kernel-trace ... (optional): executed float64 flop per launch = 64 lanes x (ADD + MUL + 2 FMA + TRANS)
-                  wave-instructions, stored as fp64_flop_per_launch (bench.py prices the fit kernel with it)
-Writes profiles/<tag>_bench_cfg3_kernel_stats.csv and profiles/<tag>_bench_cfg3_hbm_counters.json.
+Sub-directories of the raw output (each one rocprofv3 run; --pmc never combined with a trace domain other than the
+kernel trace, separate passes per counter set as MI355X_MICROARCH.md prescribes):
+  stats, stats_alone        rocprofv3 --kernel-trace --stats: the driver's bench command / the same with --depth 1
+  FETCH_SIZE, WRITE_SIZE    HBM traffic per kernel (--depth 1: the counters are device-wide)
+  FP64                      SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64: executed float64 flop per launch
+  RDREQ                     TCC_EA0_RDREQ / _32B: read requests by size (settles what FETCH_SIZE means for 8-byte loads)
+  palmer_*                  the direct kernel k_ct_palmer alone (scripts/dev/ct_time.py with CT_FFT=0)
+  cfg2_*                    BASELINE cfg2's size (bench.py --workload cfg2)
+Writes profiles/<tag>_bench_cfg3_kernel_stats.csv, _alone_kernel_stats.csv, _hbm_counters.json (bench.py reads the latest of
+these), <tag>_ct_palmer_counters.json, <tag>_bench_cfg2_kernel_stats.csv, <tag>_bench_cfg2_counters.json.
 """
 import glob
 import json
@@ -21,6 +25,7 @@ import sys
 import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, 'profiles')
 
 
 def short(name):
@@ -30,37 +35,53 @@ def short(name):
 
 
 def counters(d, counter):
-    f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
-    t = pd.read_csv(f)
+    """mean per launch of one counter, per kernel (summed over the dimensions rocprofv3 splits it into)"""
+    fs = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+    if not fs:
+        return None
+    t = pd.read_csv(fs[0])
     t = t[t.Counter_Name == counter]
-    t['k'] = t.Kernel_Name.map(short)
+    if t.empty:
+        return None
+    t = t.assign(k=t.Kernel_Name.map(short))
     per_launch = t.groupby(['k', 'Dispatch_Id']).Counter_Value.sum().reset_index()
     return per_launch.groupby('k').Counter_Value.agg(['mean', 'count'])
 
 
-def main():
-    tag, dstats, dfetch, dwrite = sys.argv[1:5]
-    dfp64 = sys.argv[5] if len(sys.argv) > 5 else None
-    f = glob.glob(os.path.join(dstats, '**', '*kernel_stats.csv'), recursive=True)[0]
-    st = pd.read_csv(f)
-    st.to_csv(os.path.join(ROOT, 'profiles', '%s_bench_cfg3_kernel_stats.csv' % tag), index=False)
-    fe, wr = counters(dfetch, 'FETCH_SIZE'), counters(dwrite, 'WRITE_SIZE')
-    out = {'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 3 --warmup 1 '
-                      '--no-cpu-baseline --depth 1 (separate passes; --depth 1 = one batch at a time: the counters are '
-                      'device-wide, kernels of overlapping batches would be charged to each other)',
+def stats_csv(d, dst):
+    fs = glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True)
+    if not fs:
+        return None
+    st = pd.read_csv(fs[0])
+    st.to_csv(dst, index=False)
+    return st
+
+
+def skip(k):
+    return k.startswith('__amd') or k.startswith('at::') or k.startswith('void at::')
+
+
+def hbm_json(raw, prefix, command):
+    fe, wr = counters(os.path.join(raw, prefix + 'FETCH_SIZE' if prefix == '' else prefix + 'FETCH'), 'FETCH_SIZE'), \
+        counters(os.path.join(raw, prefix + 'WRITE_SIZE' if prefix == '' else prefix + 'WRITE'), 'WRITE_SIZE')
+    if fe is None and wr is None:
+        return None
+    out = {'command': command,
            'note': 'units KB; corrected bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md section HBM '
-                   '(gfx950 reports half of the streamed read bytes)',
+                   '(gfx950 reports half of the streamed read bytes of wide loads; see the RDREQ note for 8-byte loads)',
            'kernels': {}}
-    for k in sorted(set(fe.index) | set(wr.index)):
-        if k.startswith('__amd') or k.startswith('at::'):
+    keys = sorted(set(fe.index if fe is not None else []) | set(wr.index if wr is not None else []))
+    for k in keys:
+        if skip(k):
             continue
-        fk = float(fe.loc[k, 'mean']) if k in fe.index else 0.0
-        wk = float(wr.loc[k, 'mean']) if k in wr.index else 0.0
-        out['kernels'][k] = {'FETCH_SIZE_KB_mean_per_launch': fk, 'launches_FETCH_SIZE': int(fe.loc[k, 'count']) if k in fe.index else 0,
-                             'WRITE_SIZE_KB_mean_per_launch': wk, 'launches_WRITE_SIZE': int(wr.loc[k, 'count']) if k in wr.index else 0,
+        fk = float(fe.loc[k, 'mean']) if fe is not None and k in fe.index else 0.0
+        wk = float(wr.loc[k, 'mean']) if wr is not None and k in wr.index else 0.0
+        out['kernels'][k] = {'FETCH_SIZE_KB_mean_per_launch': fk, 'launches_FETCH_SIZE': int(fe.loc[k, 'count']) if fe is not None and k in fe.index else 0,
+                             'WRITE_SIZE_KB_mean_per_launch': wk, 'launches_WRITE_SIZE': int(wr.loc[k, 'count']) if wr is not None and k in wr.index else 0,
                              'hbm_bytes_corrected': (2 * fk + wk) * 1024}
-    if dfp64:
-        cnt = {c: counters(dfp64, 'SQ_INSTS_VALU_%s_F64' % c) for c in ('ADD', 'MUL', 'FMA', 'TRANS')}
+    dfp = os.path.join(raw, prefix + 'FP64')
+    cnt = {c: counters(dfp, 'SQ_INSTS_VALU_%s_F64' % c) for c in ('ADD', 'MUL', 'FMA', 'TRANS')} if os.path.isdir(dfp) else {}
+    if cnt and all(v is not None for v in cnt.values()):
         out['fp64_note'] = ('fp64_flop_per_launch = 64 x (ADD_F64 + MUL_F64 + 2 FMA_F64 + TRANS_F64) wave-instructions per launch '
                             '(SQ_INSTS_VALU_*_F64, full exec mask assumed; exp / division expand into these)')
         for k in out['kernels']:
@@ -68,10 +89,70 @@ def main():
                 w = {c: float(cnt[c].loc[k, 'mean']) for c in cnt}
                 out['kernels'][k]['fp64_wave_instructions'] = w
                 out['kernels'][k]['fp64_flop_per_launch'] = 64.0 * (w['ADD'] + w['MUL'] + 2.0 * w['FMA'] + w['TRANS'])
-    with open(os.path.join(ROOT, 'profiles', '%s_bench_cfg3_hbm_counters.json' % tag), 'w') as fp:
-        json.dump(out, fp, indent=1)
-    print(st[['Name', 'Calls', 'AverageNs', 'Percentage']].head(12).to_string())
-    print({k: round(v['hbm_bytes_corrected'] / 1e6, 1) for k, v in out['kernels'].items()})
+    return out
+
+
+def main():
+    tag, raw = sys.argv[1], sys.argv[2]
+    short_flags = '--no-cpu-baseline --no-kernel-profile --no-cli-wall --spinup-s 0 --repeats 1 --steady-steps 0'
+    st = stats_csv(os.path.join(raw, 'stats'), os.path.join(PROF, '%s_bench_cfg3_kernel_stats.csv' % tag))
+    sa = stats_csv(os.path.join(raw, 'stats_alone'), os.path.join(PROF, '%s_bench_cfg3_alone_kernel_stats.csv' % tag))
+    out = hbm_json(raw, '', 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 --kernel-trace -- python3 bench.py '
+                            '--steps 3 --warmup 1 --depth 1 %s (separate passes; --depth 1 = one batch at a time: the counters are device-wide, '
+                            'kernels of overlapping batches would be charged to each other)' % short_flags)
+    if out is not None:
+        # read requests by size: FETCH_SIZE = 64 B x RDREQ; a request is 32 B (RDREQ_32B) or 64 B, so
+        # bytes actually requested = 32 * RDREQ_32B + 64 * (RDREQ - RDREQ_32B)
+        rq = counters(os.path.join(raw, 'RDREQ'), 'TCC_EA0_RDREQ_sum')
+        rq32 = counters(os.path.join(raw, 'RDREQ'), 'TCC_EA0_RDREQ_32B_sum')
+        if rq is not None and rq32 is not None:
+            out['rdreq_note'] = ('TCC_EA0_RDREQ_sum / TCC_EA0_RDREQ_32B_sum per launch: read requests to the fabric and how many of them were '
+                                 '32-byte ones; request_bytes = 32 * RDREQ_32B + 64 * (RDREQ - RDREQ_32B).  FETCH_SIZE counts every request '
+                                 'as 64 B tallied in KB, and a streaming 128-B line arrives as TWO counted... see profiles/README.md')
+            for k in out['kernels']:
+                if k in rq.index and k in rq32.index:
+                    a, b = float(rq.loc[k, 'mean']), float(rq32.loc[k, 'mean'])
+                    out['kernels'][k]['TCC_EA0_RDREQ'] = a
+                    out['kernels'][k]['TCC_EA0_RDREQ_32B'] = b
+                    out['kernels'][k]['rdreq_bytes_32_64'] = 32.0 * b + 64.0 * (a - b)
+        with open(os.path.join(PROF, '%s_bench_cfg3_hbm_counters.json' % tag), 'w') as fp:
+            json.dump(out, fp, indent=1)
+    # the direct kernel alone
+    pal = {}
+    for name, ctrs in (('palmer_FETCH', ['FETCH_SIZE']), ('palmer_WRITE', ['WRITE_SIZE']),
+                       ('palmer_VALU', ['SQ_INSTS_VALU', 'SQ_INSTS_VALU_FMA_F32', 'SQ_INSTS_VALU_MUL_F32', 'SQ_INSTS_VALU_ADD_F32'])):
+        for c in ctrs:
+            r = counters(os.path.join(raw, name), c)
+            if r is None:
+                continue
+            for k in r.index:
+                if k.startswith('k_ct_palmer'):
+                    pal.setdefault(k, {})[c + '_mean_per_launch'] = float(r.loc[k, 'mean'])
+    for k, v in pal.items():
+        if 'FETCH_SIZE_mean_per_launch' in v and 'WRITE_SIZE_mean_per_launch' in v:
+            v['hbm_bytes_corrected'] = (2 * v['FETCH_SIZE_mean_per_launch'] + v['WRITE_SIZE_mean_per_launch']) * 1024
+        if 'SQ_INSTS_VALU_FMA_F32_mean_per_launch' in v:
+            v['fp32_flop_per_launch'] = 64.0 * (2 * v['SQ_INSTS_VALU_FMA_F32_mean_per_launch'] + v.get('SQ_INSTS_VALU_MUL_F32_mean_per_launch', 0.0) +
+                                               v.get('SQ_INSTS_VALU_ADD_F32_mean_per_launch', 0.0))
+    if pal:
+        with open(os.path.join(PROF, '%s_ct_palmer_counters.json' % tag), 'w') as fp:
+            json.dump({'command': 'CT_FFT=0 rocprofv3 --pmc <one counter set per pass> --kernel-trace -- python3 scripts/dev/ct_time.py '
+                                  '(the direct kernel alone on the cfg3 planes: 24 chunks x 4096 frames x 512 vectors)',
+                       'kernels': pal}, fp, indent=1)
+    # cfg2
+    s2 = stats_csv(os.path.join(raw, 'cfg2_stats'), os.path.join(PROF, '%s_bench_cfg2_kernel_stats.csv' % tag))
+    o2 = hbm_json(raw, 'cfg2_', 'rocprofv3 --pmc ... --kernel-trace -- python3 bench.py --workload cfg2 --steps 3 --warmup 1 --depth 1 %s' % short_flags)
+    if o2 is not None:
+        with open(os.path.join(PROF, '%s_bench_cfg2_counters.json' % tag), 'w') as fp:
+            json.dump(o2, fp, indent=1)
+    for label, t in (('in pipeline', st), ('alone (--depth 1)', sa), ('cfg2', s2)):
+        if t is not None:
+            print('---', label)
+            print(t[['Name', 'Calls', 'AverageNs', 'MinNs', 'Percentage']].head(12).to_string())
+    if out is not None:
+        print({k: round(v['hbm_bytes_corrected'] / 1e6, 1) for k, v in out['kernels'].items()})
+        print({k: '%.3g' % v['fp64_flop_per_launch'] for k, v in out['kernels'].items() if 'fp64_flop_per_launch' in v})
+    print(pal)
 
 
 if __name__ == '__main__':

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the rocprofv3 material behind profiles/<tag>_*: run ON the GPU box from the repo root, e.g.
-#   gpurun --timeout 1100 -- 'bash scripts/profile_round.sh r02'
-# then, back in the container:  python scripts/make_profiles.py r02 gpurun_out/r02prof/{stats,FETCH_SIZE,WRITE_SIZE,FP64}
+#   gpurun --timeout 1100 -- 'bash scripts/profile_round.sh r03'
+# then, back in the container:  python scripts/make_profiles.py r03 gpurun_out/r03prof
 # One pass per counter set (MI355X_MICROARCH.md, HBM / rocprofv3 section); --pmc is never combined with any trace domain
 # other than the kernel trace.  The program itself follows `--` (no env / bash -c hop: the profiler's preloaded
 # library has initialised the GPU by then).
@@ -12,17 +12,41 @@ out=$root/gpurun_out/${tag}prof
 mkdir -p $out
 cd /tmp
 export TMPDIR=/tmp
+short="--no-cpu-baseline --no-kernel-profile --no-cli-wall --spinup-s 0 --repeats 1 --steady-steps 0"
 # (1) kernel statistics of the benchmark command the driver runs (the per-kernel alone / saturated launches after the
-#     timed region are left out so that the averages are the in-pipeline durations)
+#     timed region, the CPU baseline and the CLI chain are left out so that the averages are the in-pipeline durations)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- \
-    python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-profile > $out/stats.log 2>&1
+    python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-profile --no-cli-wall > $out/stats.log 2>&1
+echo "stats done"
+# (1b) the same kernels ONE BATCH AT A TIME (--depth 1: nothing overlaps): every average is the kernel's duration alone on
+#      the chip -- the "alone" fractions can be recomputed from this file without bench.py
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_alone -- \
+    python3 $root/bench.py --steps 6 --warmup 2 --depth 1 $short > $out/stats_alone.log 2>&1
+echo "stats_alone done"
 # (2-4) counters, one batch at a time (--depth 1): the counters are device-wide, kernels of overlapping batches would
 #     be charged to each other
 for pass in "FETCH_SIZE:FETCH_SIZE" "WRITE_SIZE:WRITE_SIZE" \
-            "FP64:SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64"; do
+            "FP64:SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" \
+            "RDREQ:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
     name=${pass%%:*}; ctr=${pass#*:}
     timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$name -- \
-        python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-profile --depth 1 > $out/$name.log 2>&1
+        python3 $root/bench.py --steps 3 --warmup 1 --depth 1 $short > $out/$name.log 2>&1 || echo "pass $name FAILED"
+    echo "pass $name done"
+done
+# (5) the north-star's named kernel (direct shifted products, k_ct_palmer) alone: HBM traffic and FP32 work
+for pass in "palmer_FETCH:FETCH_SIZE" "palmer_WRITE:WRITE_SIZE" "palmer_VALU:SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32"; do
+    name=${pass%%:*}; ctr=${pass#*:}
+    CT_FFT=0 REPS=3 timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$name -- \
+        python3 $root/scripts/dev/ct_time.py > $out/$name.log 2>&1 || echo "pass $name FAILED"
+    echo "pass $name done"
+done
+# (6) BASELINE cfg2's size (F + L = 1536 -> k_ct_fft<8>): statistics and HBM counters
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/cfg2_stats -- \
+    python3 $root/bench.py --workload cfg2 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-profile --no-cli-wall > $out/cfg2_stats.log 2>&1 || echo "cfg2 stats FAILED"
+for pass in "cfg2_FETCH:FETCH_SIZE" "cfg2_WRITE:WRITE_SIZE" "cfg2_FP64:SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64"; do
+    name=${pass%%:*}; ctr=${pass#*:}
+    timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$name -- \
+        python3 $root/bench.py --workload cfg2 --steps 3 --warmup 1 --depth 1 $short > $out/$name.log 2>&1 || echo "pass $name FAILED"
     echo "pass $name done"
 done
 tail -c 300 $out/stats.log

@@ -100,13 +100,14 @@ def parse():
     ap.add_argument('--dev-skip-fits', action='store_true', help='DEVELOPMENT ONLY (invalid as a benchmark): leave the fits and the relaxation kernel out, to see the floor the C(t) side alone sets')
     ap.add_argument('--hist-on-main', action='store_true', help='keep the histogram kernel in line with C(t) (only the pack runs beside it)')
     ap.add_argument('--ct-fft', type=int, default=-1, help='kernel 1: 2 = real-input FFT (k_ct_rfft) where it applies, 1 = complex FFT (k_ct_fft), 0 = direct (k_ct_palmer); -1 = library default (2)')
+    ap.add_argument('--ct-traceless', type=int, default=0, help='1: k_ct_rfft<12> with five transforms (traceless components; library option ct_traceless, default off)')
     ap.add_argument('--depth', type=int, default=5, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cli-wall', action='store_true', help='skip the wall-clock run of the drop-in CLI chain (run-all.bash Step 3 + Step 4) on the same workload')
     ap.add_argument('--no-kernel-profile', action='store_true', help='skip the per-kernel alone / saturated timings after the timed region (the `kernels` entries then only carry in-pipeline durations)')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
     ap.add_argument('--all-ranks-on-device0', action='store_true', help='rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)')
-    ap.add_argument('--cpu-sample-vectors', type=int, default=4, help='vectors of the 1-thread reference-equivalent CPU sample')
+    ap.add_argument('--cpu-sample-vectors', type=int, default=8, help='vectors of the 1-thread reference-equivalent CPU sample')
     ap.add_argument('--cpu-allcore-vectors', type=int, default=64, help='vectors of the all-core / CPU-FFT samples (>= 64: not cache-resident)')
     return ap.parse_args()
 
@@ -244,7 +245,7 @@ def cli_wall(vecs_host, s, cfg, cpu):
         if cpu and cpu.get('value'):
             triples = synth.exact_triples(s['R'], s['F'], vecs_host.shape[1])
             out['cpu_reference_chain_s_extrapolated'] = round(triples / cpu['value'], 1)
-            out['cpu_note'] = 'exact triples of the workload / the 1-thread whole-path rate of cpu_baseline (a %s-vector sample)' % cpu.get('sample', '?').split(' of the')[0][-3:].strip()
+            out['cpu_note'] = 'exact triples of the workload / the 1-thread whole-path rate of cpu_baseline (measured on a sample of the same vectors)'
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out
@@ -254,17 +255,17 @@ def use_rfft_bench(args, s):
     return args.ct_fft in (-1, 2) and 4096 < s['F'] + s['L'] <= 8192
 
 
-def fft_exec_flop(s, V, real_input=False):
+def fft_exec_flop(s, V, real_input=False, traceless=False):
     """executed float64 work per launch (formula; the committed PMC pass replaces it when it has the kernel).
     k_ct_fft: 4 complex M-point transforms (5 M log2 M flop each), the power spectra of 3 packed pairs (12 flop per
     frequency each) and the 6 products per frame, per (chunk, vector).  k_ct_rfft: 7 complex transforms of H = M/2 points,
     two twiddle passes (6 flop per point) per transform and the real-signal spectrum step (24 flop per frequency) for the
-    six signals (five in the traceless form of k_ct_rfft<12>: 6 transforms in all)."""
+    six signals (five with the option ct_traceless of k_ct_rfft<12>: 6 transforms in all)."""
     need = s['F'] + s['L']
     M = 2048 if need <= 2048 else (4096 if need <= 4096 else (6144 if need <= 6144 else 8192))
     if real_input:
         H = M // 2
-        nf = 5 if M == 6144 else 6          # traceless form (5 forward transforms) where the chunk allows it (k_ct_rfft<12>)
+        nf = 5 if (traceless and M == 6144) else 6
         return M, s['R'] * V * ((nf + 1) * (5 * H * np.log2(H) + 12 * H) + nf * 24 * H + 6 * s['F'])
     return M, s['R'] * V * (4 * 5 * M * np.log2(M) + 3 * 12 * M + 6 * s['F'])
 
@@ -312,6 +313,8 @@ def main():
         ctx.set_option('fit_lds', args.fit_lds)
     if args.ct_fft >= 0:
         ctx.set_option('ct_fft', args.ct_fft)
+    if args.ct_traceless:
+        ctx.set_option('ct_traceless', 1)
     triples = synth.exact_triples(s['R'], s['F'], V)
     pkw = dict(q_rot=q, Diso=synth.DISO, aniso=aniso, field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA)
     pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], depth=args.depth,
@@ -546,13 +549,13 @@ def main():
             return e
 
         if use_fft:
-            M, xflop = fft_exec_flop(s, V, use_rfft)
+            M, xflop = fft_exec_flop(s, V, use_rfft, bool(args.ct_traceless))
             pe = prof_entry(prof, kname)
             xsrc = 'formula (bench.py:fft_exec_flop)'
             if pe and pe.get('fp64_flop_per_launch'):
                 xflop, xsrc = pe['fp64_flop_per_launch'], 'PMC float64 instruction counts of the committed profile %s' % prof_src
             form = ('Wiener-Khinchin on real input: %s float64 complex transforms of %d points (half the padded length), two workgroups per CU'
-                    % ('5 (traceless components; the trace term from prefix sums) + 1' if M == 6144 else '6 + 1', M // 2)
+                    % ('5 (traceless components; the trace term from window sums) + 1' if (bool(args.ct_traceless) and M == 6144) else '6 + 1', M // 2)
                     if use_rfft else 'Wiener-Khinchin: 6 float64 autocorrelations by FFT, whole %d-point transform resident in LDS' % M)
             entry(kname, 'valu-fp64 (float64 vector FMA; latency- and LDS-exchange-limited)', xflop, 1e12, PEAK_FP64_TFLOPS, 'TFLOP/s',
                   ct_ms, alone.get('ct'), formulation=form, work_source=xsrc,

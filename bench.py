@@ -101,6 +101,9 @@ def parse():
     ap.add_argument('--hist-on-main', action='store_true', help='keep the histogram kernel in line with C(t) (only the pack runs beside it)')
     ap.add_argument('--ct-fft', type=int, default=-1, help='kernel 1: 2 = real-input FFT (k_ct_rfft) where it applies, 1 = complex FFT (k_ct_fft), 0 = direct (k_ct_palmer); -1 = library default (2)')
     ap.add_argument('--ct-traceless', type=int, default=0, help='1: k_ct_rfft<12> with five transforms (traceless components; library option ct_traceless, default off)')
+    ap.add_argument('--group', type=int, default=32, help='batches whose fits / relaxation run as ONE merged launch behind their C(t) kernels (GroupedPipeline; a run of K steps uses groups of min(K, group)); 1 = every batch launches its own fits (DevicePipeline, --depth of them in flight)')
+    ap.add_argument('--no-group-overlap', action='store_true', help='grouped schedule: the next group\'s C(t) kernels wait for the merged fit launch (strict phases)')
+    ap.add_argument('--no-permute', action='store_true', help='grouped schedule: dispatch the merged launch in natural residue order')
     ap.add_argument('--depth', type=int, default=5, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cli-wall', action='store_true', help='skip the wall-clock run of the drop-in CLI chain (run-all.bash Step 3 + Step 4) on the same workload')
@@ -276,7 +279,7 @@ def main():
     import torch.distributed as dist
     from spinrelax_amd import synth
     from spinrelax_amd.hip import Context
-    from spinrelax_amd.pipeline import DevicePipeline
+    from spinrelax_amd.pipeline import DevicePipeline, GroupedPipeline
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -317,14 +320,21 @@ def main():
         ctx.set_option('ct_traceless', 1)
     triples = synth.exact_triples(s['R'], s['F'], V)
     pkw = dict(q_rot=q, Diso=synth.DISO, aniso=aniso, field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA)
-    pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], depth=args.depth,
-                          stream=torch.cuda.Stream(device=dev, priority=args.main_priority), reserve_cus=args.reserve_cus, aux_cus=args.aux_cus,
-                          fit_priority=args.fit_priority, plane_buffers=args.plane_buffers,
-                          fits_on_reserved_only=bool(args.fits_on_reserved_only), hist_on_aux=not args.hist_on_main, **pkw)
+    grouped = args.group > 1 and args.depth > 1 and not args.reserve_cus and not args.aux_cus and not args.hist_on_main
+    if grouped:
+        pipe = GroupedPipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], group=args.group, overlap=not args.no_group_overlap,
+                               stream=torch.cuda.Stream(device=dev, priority=args.main_priority), plane_buffers=args.plane_buffers, **pkw)
+        pipe.permute = not args.no_permute
+        pipe.dev_skip_fits = bool(args.dev_skip_fits)
+    else:
+        pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], depth=args.depth,
+                              stream=torch.cuda.Stream(device=dev, priority=args.main_priority), reserve_cus=args.reserve_cus, aux_cus=args.aux_cus,
+                              fit_priority=args.fit_priority, plane_buffers=args.plane_buffers,
+                              fits_on_reserved_only=bool(args.fits_on_reserved_only), hist_on_aux=not args.hist_on_main, **pkw)
+        if args.dev_skip_fits:
+            pipe.stage_fit = lambda s=None: None
+            pipe.stage_relax = lambda s=None: None
     stream = pipe.main
-    if args.dev_skip_fits:
-        pipe.stage_fit = lambda s=None: None
-        pipe.stage_relax = lambda s=None: None
     ctx.set_stream(stream.cuda_stream)
 
     with torch.cuda.stream(stream):
@@ -342,16 +352,12 @@ def main():
                 return None
             with torch.cuda.stream(gstream):
                 gstream.wait_event(slot.done)
-                for name in ('Ct', 'dCt', 'hist'):
+                for name in ('Ct', 'dCt', 'hist', 'relax'):          # a slot is one batch (DevicePipeline) or a group of them
                     tns = getattr(slot, name)
-                    key = (id(slot), name)
+                    key = (id(slot), name, tuple(tns.shape))
                     if key not in gbuf:
                         gbuf[key] = [torch.empty_like(tns) for _ in range(world)]
                     dist.all_gather(gbuf[key], tns)
-                key = (id(slot), 'relax')
-                if key not in gbuf:
-                    gbuf[key] = [torch.empty_like(slot.relax) for _ in range(world)]
-                dist.all_gather(gbuf[key], slot.relax)
                 ev = torch.cuda.Event()
                 ev.record(gstream)
             return ev
@@ -368,9 +374,10 @@ def main():
             dist.barrier()
         # clock spin-up (untimed, same work as the timed steps): run until --spinup-s seconds have passed
         spin_steps, t_spin = 0, time.perf_counter()
+        spin_chunk = args.steps if grouped else 10     # grouped: the spin-up runs groups of the size the timed region uses
         while time.perf_counter() - t_spin < args.spinup_s:
-            run_batches(10)
-            spin_steps += 10
+            run_batches(spin_chunk)
+            spin_steps += spin_chunk
         spin_s = time.perf_counter() - t_spin
         run_batches(args.warmup)
         nfev0 = pipe.nfev_total
@@ -418,12 +425,14 @@ def main():
             return out
         hp = _pairs(2, 3) if q is not None else []
         hist_ms = float(np.mean(hp)) if hp else None
-        fit_ms = None if args.dev_skip_fits else float(np.mean([e[4].elapsed_time(e[5]) for e in events]))
+        fp = _pairs(4, 5)                # grouped schedule: one merged launch per group, recorded on its first batch's entry
+        fit_ms = None if (args.dev_skip_fits or not fp) else float(np.mean(fp))
     best = pipe.fit_best
     nfev_by_order = {str(k): int(np.sum(v)) for k, v in pipe.nfev_last.items()}
     nfits_by_order = {str(k): int(np.size(v)) for k, v in pipe.nfev_last.items()}
     nfev_step = nfev_timed / max(1, args.steps * max(1, args.repeats))
     depth_used, reserve_used = pipe.depth, pipe.reserve_cus
+    group_used = min(args.group, args.steps) if grouped else 1
     listDoG = pipe.listDoG
     del events, gbuf
     pipe.close()
@@ -580,7 +589,8 @@ def main():
             sat = alone.get('fit_saturated_per_batch')
             tref = sat or alone.get('fit') or fit_ms
             e = dict(bound='valu-fp64 issue + latency (one workgroup per residue, hundreds of dependent solver iterations)',
-                     in_pipeline_ms=fit_ms, alone_ms=alone.get('fit'), saturated_ms_per_batch=sat,
+                     in_pipeline_ms=fit_ms, in_pipeline_batches_per_launch=group_used,
+                     in_pipeline_ms_per_batch=fit_ms / group_used, alone_ms=alone.get('fit'), saturated_ms_per_batch=sat,
                      cu_ms_per_batch=sat * N_CU if sat else None, residues=V, evaluations_per_batch=nfev_step,
                      residues_per_s=V / (tref * 1e-3), evaluations_per_s=nfev_step / (tref * 1e-3),
                      peak=PEAK_FP64_TFLOPS, unit='TFLOP/s',
@@ -639,7 +649,11 @@ def main():
                                    '%s, fits 2/3/5/7/9 params, 1 field' % (cfg, s['frames'], V, s['R'], s['F'], s['L'],
                                                                            'axisymmetric D + q_ext + 72x36 histogram' if cfg == 3 else 'isotropic D'),
                        'vectors_per_gpu': V, 'exact_triples_per_gpu': triples, 'sharding': 'vectors (no data-path collective; all-gather of results)',
-                       'batches_in_flight': depth_used, 'cus_reserved_for_fits': reserve_used},
+                       'schedule': ('grouped: C(t) / histogram / chunk statistics of %d batches back to back, then ONE merged model-order search + '
+                                    'relaxation launch over their %d residues (dispatched in a fixed pseudo-random order); next group%s'
+                                    % (group_used, group_used * V, ' overlaps it' if not args.no_group_overlap else ' waits for it'))
+                                   if grouped else 'per batch: every batch launches its own fits, %d batches in flight' % depth_used,
+                       'batches_per_group': group_used, 'batches_in_flight': group_used if grouped else depth_used, 'cus_reserved_for_fits': reserve_used},
             'roofline': roofline,
             'kernels': kernels,
             'stages_alone_ms': {k: round(v, 4) for k, v in alone.items()},

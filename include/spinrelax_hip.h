@@ -37,7 +37,7 @@ extern "C" {
 
 typedef struct sr_ctx sr_ctx;
 
-#define SR_ABI_VERSION 3
+#define SR_ABI_VERSION 4
 
 /* ---- context, memory, timing ------------------------------------------------------------- */
 int          sr_abi_version(void);
@@ -246,6 +246,19 @@ int sr_expfit_order_search_f64_dev(sr_ctx *, const double *t, const double *C, c
                                    double tau_max, double chi_threshold, double *work, double *popt, double *dP,
                                    double *chisq, int *status, int *nfev, int *best, double *sel_S2, double *sel_C,
                                    double *sel_tau, double *sel_chi, int *sel_K);
+/* The same for SEVERAL batches of residues in one launch (the pipeline merges the searches of a group of trajectory shards:
+ * the per-residue loop of calculate-fitted-Ct.py:161-178 over all of them).  A launch lasts as long as its slowest residue and a
+ * residue's cost is not known beforehand (2 to 9 parameters, 20 to 900 function evaluations): merged launches keep the chip
+ * full while the stragglers of every batch run.
+ *   t_rows          1: one time axis (L values) shared by every residue; nRes: a row per residue as above
+ *   dispatch_order  DEVICE, nRes residue indices, or NULL: workgroup b solves residue dispatch_order[b].  Results are stored
+ *                   at the residue's own index whatever the order; a permutation spreads residues that are expensive for the
+ *                   same reason (the same position in every batch) over the chip instead of over one part of it. */
+int sr_expfit_order_search_batched_f64_dev(sr_ctx *, const double *t, int t_rows, const double *C, const double *sigma, int nRes,
+                                           int L, const int *orders, int nOrders, const double *tau_guess, int tau_guess_rows,
+                                           double tau_max, double chi_threshold, const int *dispatch_order, double *work,
+                                           double *popt, double *dP, double *chisq, int *status, int *nfev, int *best,
+                                           double *sel_S2, double *sel_C, double *sel_tau, double *sel_chi, int *sel_K);
 /* the same with HOST pointers throughout (staged through the context's work space, synchronous) */
 int sr_expfit_order_search_f64(sr_ctx *, const double *t, const double *C, const double *sigma, int nRes, int L,
                                const int *orders, int nOrders, const double *tau_guess, int tau_guess_rows,

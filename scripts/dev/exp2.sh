@@ -1,0 +1,20 @@
+set -e
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/exp2
+timeout -k 10 500 python -m pytest tests/test_gpu_pipeline.py -x -q -k "grouped or batched_order" > gpurun_out/exp2/pytest.log 2>&1 || { tail -30 gpurun_out/exp2/pytest.log; exit 1; }
+tail -3 gpurun_out/exp2/pytest.log
+run() { tag=$1; shift; timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cli-wall --no-kernel-profile "$@" > gpurun_out/exp2/$tag.json 2> gpurun_out/exp2/$tag.err; python - <<P
+import json
+d=json.load(open('gpurun_out/exp2/$tag.json'))
+k=d['kernels']
+print('$tag', 'step %.3f'%d['ms_per_step'], ['%.2f'%x for x in d['timed_region_samples_ms_per_step']], 'steady %.3f'%d['ms_per_step_steady'], 'inpipe ct %.2f hist %.2f fit %.2f'%(k['k_ct_rfft']['in_pipeline_ms'], k['k_vechist']['in_pipeline_ms'], k['k_order_search']['in_pipeline_ms']), d['fit']['evaluations_per_batch'], flush=True)
+P
+}
+run g1 --group 1
+run g32
+run g32_strict --no-group-overlap
+run g32_noperm --no-permute
+run g16 --group 16
+run g10 --group 10
+run g1b --group 1
+run g32b

@@ -68,6 +68,11 @@ SIGNATURES = {
     'sr_expfit_order_search_f64_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                                c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    # (ctx, t, t_rows, C, sigma, nRes, L, orders, nOrders, tau_guess, tau_rows, tau_max, chi_thr, dispatch_order, work, popt, ...)
+    'sr_expfit_order_search_batched_f64_dev': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                                       c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                       c_void_p]),
     'sr_expfit_order_search_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                            c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -112,7 +117,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 LIB_PATH = os.environ.get('SPINRELAX_HIP_LIB', LIB_PATH)      # alternative build of the same ABI
 
 

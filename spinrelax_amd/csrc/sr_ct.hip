@@ -939,8 +939,16 @@ template <bool TR> __device__ __forceinline__ double rfft_weight4(int c)
     return c == 0 ? 1.0 / 24.0 : (c == 1 ? 0.125 : (c == 5 ? 1.0 / 12.0 : 0.5));
 }
 
+// SR_RFFT_NUM_VGPR: register budget of the kernel below the 256 that two waves per SIMD allow.  (clang's amdgpu_num_vgpr counts
+// in units of TWO registers on gfx90a and later -- the backend doubles the value for the unified VGPR/AGPR file and silently
+// drops a request above the occupancy bound, so "240" must be written as 120.)
+#ifdef SR_RFFT_NUM_VGPR
+#define SR_RFFT_VGPR_ATTR __attribute__((amdgpu_num_vgpr(SR_RFFT_NUM_VGPR / 2)))
+#else
+#define SR_RFFT_VGPR_ATTR
+#endif
 template <int N1, bool HALF, bool TR>
-__global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
+__global__ __launch_bounds__(256, 2) SR_RFFT_VGPR_ATTR void k_ct_rfft(CtRfftArgs a)
 {
     extern __shared__ __align__(16) unsigned char fft_smem[];
     cplx *lds = reinterpret_cast<cplx *>(fft_smem);

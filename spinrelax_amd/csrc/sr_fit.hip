@@ -1386,6 +1386,9 @@ struct SearchArgs {
     double *sel_S2, *sel_C, *sel_tau, *sel_chi;   // (nRes), (nRes,Kmax), (nRes,Kmax), (nRes): components sorted by tau
     int *sel_K;                       // (nRes) number of components of the selected model (0 = none)
     double *fws;                      // (nRes, L) weights when a residue does not fit into LDS
+    int64_t t_stride;                 // L, or 0: one time axis shared by every residue
+    const int *order;                 // null, or nRes residue indices: workgroup b solves residue order[b] (results stay at the
+                                      // residue's own index; only WHEN a residue starts changes)
 };
 
 // numpy.mean of n <= 128 contiguous float64 values (pairwise summation of numpy/_core/src/umath/loops_utils.h.src)
@@ -1505,13 +1508,13 @@ __device__ __noinline__ void search_order(const R T, const SearchArgs &a, int j,
 template <int NMAX, int W, bool LDS>
 __global__ __launch_bounds__(W * 64, SR_FIT_WAVES_EU) void k_order_search(SearchArgs a)
 {
-    const int res = blockIdx.x;
+    const int res = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x;
     Residue<W, LDS> T;
     T.L = a.L;
     T.tid = tid;
     const double *sg_res = a.sigma ? a.sigma + (int64_t)res * a.L : nullptr;
-    T.stage(a.t + (int64_t)res * a.L, a.y + (int64_t)res * a.L, sg_res, LDS ? nullptr : a.fws + (int64_t)res * a.L);
+    T.stage(a.t + (int64_t)res * a.t_stride, a.y + (int64_t)res * a.L, sg_res, LDS ? nullptr : a.fws + (int64_t)res * a.L);
 
     const int ns = a.L < 10 ? a.L : 10;                 // nSample = 10, fitting_Ct_functions.py:359
     const double avgBeg = np_mean_y(T, 0, ns);
@@ -1733,7 +1736,19 @@ int sr_expfit_order_search_f64_dev(sr_ctx *ctx, const double *t, const double *C
                                    double *chisq, int *status, int *nfev, int *best, double *sel_S2, double *sel_C,
                                    double *sel_tau, double *sel_chi, int *sel_K)
 {
+    return sr_expfit_order_search_batched_f64_dev(ctx, t, nRes, C, sigma, nRes, L, orders, nOrders, tau_guess, tau_guess_rows, tau_max,
+                                                  chi_threshold, nullptr, work, popt, dP, chisq, status, nfev, best, sel_S2, sel_C,
+                                                  sel_tau, sel_chi, sel_K);
+}
+
+int sr_expfit_order_search_batched_f64_dev(sr_ctx *ctx, const double *t, int t_rows, const double *C, const double *sigma, int nRes,
+                                           int L, const int *orders, int nOrders, const double *tau_guess, int tau_guess_rows,
+                                           double tau_max, double chi_threshold, const int *dispatch_order, double *work,
+                                           double *popt, double *dP, double *chisq, int *status, int *nfev, int *best,
+                                           double *sel_S2, double *sel_C, double *sel_tau, double *sel_chi, int *sel_K)
+{
     SR_CHECK_CTX(ctx);
+    SR_REQUIRE(t_rows == 1 || t_rows == nRes, -3, "sr_expfit_order_search_batched_f64_dev: t_rows must be 1 or nRes");
     SR_REQUIRE(t && C && orders && tau_guess && popt && dP && chisq && status && nfev && best && sel_S2 && sel_C && sel_tau &&
                    sel_chi && sel_K, -2, "sr_expfit_order_search_f64_dev: null pointer");
     SR_REQUIRE(nRes >= 1 && L >= 1 && nOrders >= 1 && nOrders <= kMaxOrders, -3,
@@ -1757,6 +1772,7 @@ int sr_expfit_order_search_f64_dev(sr_ctx *ctx, const double *t, const double *C
         if (!fws) return -5;
     }
     a.t = t; a.y = C; a.sigma = sigma; a.nRes = nRes; a.L = L; a.nOrders = nOrders;
+    a.t_stride = t_rows == 1 ? 0 : L; a.order = dispatch_order;
     a.tau_guess = tau_guess; a.tau_stride = tau_guess_rows == 1 ? 0 : off;
     a.tau_max = tau_max; a.chi_thr = chi_threshold; a.ftol = a.xtol = a.gtol = 1e-8;
     a.Pmax = pmax; a.Kmax = pmax / 2;

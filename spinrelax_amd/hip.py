@@ -372,6 +372,18 @@ class Context:
                                                       popt_ptr, dP_ptr, chisq_ptr, status_ptr, nfev_ptr, best_ptr, S2_ptr, C_ptr,
                                                       tau_ptr, chi_ptr, K_ptr), 'sr_expfit_order_search_f64_dev')
 
+    def order_search_batched_dev(self, t_ptr, t_rows, y_ptr, sigma_ptr, nRes, L, orders, tau_guess_ptr, tau_rows, tau_max, chi_threshold,
+                                 popt_ptr, dP_ptr, chisq_ptr, status_ptr, nfev_ptr, best_ptr, S2_ptr, C_ptr, tau_ptr, chi_ptr, K_ptr,
+                                 work_ptr=None, dispatch_order_ptr=None):
+        """the model-order search of several batches' residues in one launch (sr_expfit_order_search_batched_f64_dev):
+        t_rows = 1 shares one time axis, dispatch_order (device int32, nRes) permutes the order in which residues start"""
+        orders = np.ascontiguousarray(orders, dtype=np.int32)
+        check(self.lib.sr_expfit_order_search_batched_f64_dev(self.h, t_ptr, t_rows, y_ptr, sigma_ptr, nRes, L, _ptr(orders), orders.size,
+                                                              tau_guess_ptr, tau_rows, float(tau_max), float(chi_threshold),
+                                                              dispatch_order_ptr, work_ptr, popt_ptr, dP_ptr, chisq_ptr, status_ptr,
+                                                              nfev_ptr, best_ptr, S2_ptr, C_ptr, tau_ptr, chi_ptr, K_ptr),
+              'sr_expfit_order_search_batched_f64_dev')
+
     def relax_dev(self, model, D, E, omega_ptr, fDD_ptr, fCSA_ptr, tf_ptr, gr_ptr, nRes, Kmax, zeta, S2_ptr, C_ptr, tau_ptr,
                   K_ptr, B, binvecs_ptr, weights_ptr, noe_mode, out_ptr, Jout_ptr=None, stats_ptr=None):
         Dh = _f64(np.atleast_1d(D))

@@ -554,3 +554,398 @@ class DevicePipeline:
     @property
     def hist(self):
         return self.slots[0].hist
+
+
+# ======================================================================================================================
+# Grouped schedule: throughput halves of G batches back to back, then ONE merged launch for their latency halves
+# ======================================================================================================================
+class _BatchView:
+    """What the stage functions need of one batch inside a group (views into the group's contiguous buffers)."""
+    __slots__ = ('Ct', 'dCt', 'CtT', 'dCtT', 'hist', 'vecsum', 'outer', 'psum', 'result', 'relax_out', 'index')
+
+
+class _Group:
+    """Device buffers, pinned mirrors and stream of a GROUP of up to G batches.  Inputs of the merged launches are
+    contiguous over the group's residues (batch j = rows j V .. (j + 1) V), results are laid out for the g batches a
+    launch really holds (the residue axis has length g V)."""
+
+    def __init__(self, ctx, dev, G, V, L, R, nbins, nO, Pmax, E, stream):
+        f64 = dict(device=dev, dtype=torch.float64)
+        i32 = dict(device=dev, dtype=torch.int32)
+        self.G, self.V, self.L = G, V, L
+        self._shape = (nO, Pmax, Pmax // 2, E)
+        GV = G * V
+        self._Ct = torch.empty((G, L, V), **f64)
+        self._dCt = torch.empty((G, L, V), **f64)
+        self.CtT = torch.empty((GV, L), **f64)
+        self.dCtT = torch.empty((GV, L), **f64)
+        self._hist = torch.empty((GV, nbins), **f64)
+        self.vecsum = torch.empty((GV, 3), **f64)
+        self.outer = torch.empty((G, R, V, 6), **f64)
+        self.fitwork = torch.empty((GV, L), **f64)
+        nd, ni = self._sizes(G)
+        self.dres = torch.empty((nd,), **f64)
+        self.ires = torch.empty((ni,), **i32)
+        self._ctx = ctx
+        self.h_dres, self._h_dres_addr = _pinned_array(ctx, nd, np.float64)
+        self.h_ires, self._h_ires_addr = _pinned_array(ctx, ni, np.int32)
+        self.stream = stream
+        self.g = 0                 # batches of the group in flight / last collected
+        self.first = 0             # index (in the run) of the group's first batch
+        self.done = None
+        self.guard = None
+        self.busy = False
+        self.batches = []
+        self._views = {}
+
+    def _layouts(self, g):
+        nO, Pmax, Kmax, E = self._shape
+        n = g * self.V
+        return ((('popt', (nO, n, Pmax), 1), ('dP', (nO, n, Pmax), 1), ('chisq', (nO, n), 1), ('S2', (n,), 0), ('chi', (n,), 0),
+                 ('C', (n, Kmax), 0), ('tau', (n, Kmax), 0), ('relax', (E, n, 4, 2), 1)),
+                (('status', (nO, n), 1), ('nfev', (nO, n), 1), ('best', (n,), 0), ('K', (n,), 0)))
+
+    def _sizes(self, g):
+        dl, il = self._layouts(g)
+        return sum(int(np.prod(sh)) for _, sh, _ in dl), sum(int(np.prod(sh)) for _, sh, _ in il)
+
+    def views(self, g):
+        """device views of the result buffers for a launch over g batches"""
+        if g not in self._views:
+            out = {}
+            for buf, layout in zip((self.dres, self.ires), self._layouts(g)):
+                o = 0
+                for name, sh, _ in layout:
+                    n = int(np.prod(sh))
+                    out[name] = buf[o:o + n].view(sh)
+                    o += n
+            self._views[g] = out
+        return self._views[g]
+
+    # what a device-side consumer of a finished group reads (bench.py's all-gather): the g batches in flight
+    @property
+    def Ct(self):
+        return self._Ct[:self.g]
+
+    @property
+    def dCt(self):
+        return self._dCt[:self.g]
+
+    @property
+    def hist(self):
+        return self._hist[:self.g * self.V]
+
+    @property
+    def relax(self):
+        return self.views(self.g)['relax']
+
+    def batch(self, j):
+        V = self.V
+        b = _BatchView()
+        b.Ct, b.dCt = self._Ct[j], self._dCt[j]
+        b.CtT, b.dCtT = self.CtT[j * V:(j + 1) * V], self.dCtT[j * V:(j + 1) * V]
+        b.hist, b.vecsum, b.outer = self._hist[j * V:(j + 1) * V], self.vecsum[j * V:(j + 1) * V], self.outer[j]
+        b.psum = None
+        b.result = b.relax_out = None
+        b.index = j
+        return b
+
+    def host_results(self):
+        """per batch: COPIES of the pinned mirrors, split along the residue axis"""
+        g, V = self.g, self.V
+        nd, ni = self._sizes(g)
+        whole = {}
+        for buf, layout in zip((self.h_dres[:nd].copy(), self.h_ires[:ni].copy()), self._layouts(g)):
+            o = 0
+            for name, sh, axis in layout:
+                n = int(np.prod(sh))
+                whole[name] = (buf[o:o + n].reshape(sh), axis)
+                o += n
+        out = []
+        for j in range(g):
+            r = {}
+            for name, (arr, axis) in whole.items():
+                r[name] = arr[j * V:(j + 1) * V] if axis == 0 else arr[:, j * V:(j + 1) * V]
+            out.append(r)
+        return out
+
+    def release(self):
+        for name in ('_h_dres_addr', '_h_ires_addr'):
+            addr = getattr(self, name, None)
+            if addr:
+                self._ctx.host_free(addr)
+                setattr(self, name, None)
+        self.h_dres = self.h_ires = None
+
+
+class GroupedPipeline(DevicePipeline):
+    """The same stages as DevicePipeline, scheduled for throughput over MANY batches (trajectory shards):
+
+      phase 1   pack, C(t), histogram, chunk statistics of `group` batches back to back (two C(t) streams, the bandwidth
+                kernels beside them) -- no fit is in flight, so the C(t) grids have the chip's registers to themselves
+                and the pack / histogram waves find slots beside them;
+      phase 2   ONE model-order search over the group's g x V residues (sr_expfit_order_search_batched_f64_dev), one
+                relaxation launch, one pair of copies to pinned memory.
+
+    Why: a fit launch lasts as long as its slowest residue (one nine-parameter fit that never converges: ~300 evaluations,
+    6.5 ms) while the median residue needs 0.3 ms.  Launched per batch, the stragglers of ~3 batches are always in flight
+    and their workgroups (256 VGPRs) time-share the CUs with the C(t) grids: measured 2.28 ms per batch in steady state
+    against 1.15 ms (phase 1 alone) + 0.71 ms (fits with the chip to themselves).  Merged over a group, the stragglers of
+    all its batches run side by side while the cheap residues fill the rest of the chip.  The residues of the merged
+    launch are dispatched in a fixed pseudo-random order: residues that are expensive for the same reason sit at the
+    same index in every batch, and consecutive workgroup indices are served by the same part of the chip (natural
+    order: 32 ms for 20 batches; permuted: 21.5 ms).  Results are those of DevicePipeline bit for
+    bit (a residue's fit does not depend on what else is in the launch).
+
+    The next group's phase 1 is queued behind the merged launch without waiting for it (`overlap`), so the tail of one
+    group's stragglers is covered by the next group's C(t) kernels; two group buffers alternate."""
+
+    def __init__(self, ctx, device, frames, V, R, F, dt, group=32, overlap=True, psum_buffers=3, **kw):
+        kw = dict(kw)
+        kw['depth'] = max(2, int(psum_buffers))          # the base class's slots: only their raw-sum buffers are used (a rotating pool)
+        for name in ('reserve_cus', 'aux_cus'):
+            if kw.get(name):
+                raise ValueError('GroupedPipeline runs its phases on the whole chip: %s is not supported' % name)
+        super().__init__(ctx, device, frames, V, R, F, dt, **kw)
+        self.group = max(1, int(group))
+        self.overlap = bool(overlap)
+        self.permute = True            # dispatch the merged launch's residues in a fixed pseudo-random order
+        self.dev_skip_fits = False     # development only
+        self.pool = self.slots
+        self.NP = len(self.pool)
+        self._psum_free = [None] * self.NP
+        self.tail = torch.cuda.Stream(device=device)
+        Pmax = max(self.listDoG)
+        E = len(self.fields)
+        self.groups = [_Group(ctx, device, self.group, V, self.L, R, self.nbins, len(self.listDoG), Pmax, E,
+                              torch.cuda.Stream(device=device)) for _ in range(2)]
+        self.slots = self.groups                          # what a caller iterates over to set up per-slot consumers
+        self._perm = {}
+        self._fcsa = {}
+        self._last_fin = None
+        self._last_hist = None
+        self._prev_done = None
+        self._nbatch = 0
+        torch.cuda.synchronize(device)
+
+    def group_sizes(self, nb):
+        """how a run of nb batches is cut into groups (at most `group` each).  `sizes_override` (development): explicit list."""
+        ov = getattr(self, 'sizes_override', None)
+        if ov:
+            out, rem = [], nb
+            for g in ov:
+                if rem <= 0:
+                    break
+                g = min(int(g), rem, self.group)
+                out.append(g)
+                rem -= g
+            while rem > 0:
+                g = min(self.group, rem)
+                out.append(g)
+                rem -= g
+            return out
+        out, rem = [], nb
+        while rem > 0:
+            g = min(self.group, rem)
+            out.append(g)
+            rem -= g
+        return out
+
+    def _dispatch_order(self, g):
+        """fixed pseudo-random permutation of the g V residues of a merged launch (device int32)"""
+        if g not in self._perm:
+            n = g * self.V
+            p = np.random.RandomState(20240 + g).permutation(n).astype(np.int32) if g > 1 else np.arange(n, dtype=np.int32)
+            self._perm[g] = torch.from_numpy(p).to(self.dev)
+        return self._perm[g]
+
+    def _fcsa_for(self, g):
+        if g not in self._fcsa:
+            self._fcsa[g] = self._relax_dev[2].repeat(1, g).contiguous() if self._relax_dev[2].dim() == 2 else self._relax_dev[2].repeat(g).contiguous()
+        return self._fcsa[g]
+
+    def _front_grouped(self, vecs, kk, grp, j, events, pack_next):
+        bv = grp.batches[j]
+        b = kk % self.NB
+        buf = self.soa_bufs[b]
+        pi = kk % self.NP
+        bv.psum = self.pool[pi].psum
+        if not self._packed:
+            self.ctx.set_stream(self.aux.cuda_stream)
+            with torch.cuda.stream(self.aux):
+                if self._ct_done_ev[b] is not None:
+                    self.aux.wait_event(self._ct_done_ev[b])
+                self.stage_pack(vecs, buf)
+                self._packed_ev[b] = torch.cuda.Event()
+                self._packed_ev[b].record(self.aux)
+        self._packed = False
+        main = self.main_alt if (kk % 2 == 1 and self.main_alt is not None) else self.main
+        self.ctx.set_stream(main.cuda_stream)
+        with torch.cuda.stream(main):
+            main.wait_event(self._packed_ev[b])
+            if self._psum_free[pi] is not None:
+                main.wait_event(self._psum_free[pi])      # the chunk statistics of batch kk - NP have read these raw sums
+            if j < 2 and not self.overlap and self._prev_done is not None:
+                main.wait_event(self._prev_done)          # strict phases: the previous group's merged launch has finished (both C(t) streams)
+            if events is not None:
+                events[0].record(main)
+            # (Offsetting the two C(t) streams by half a launch -- first launch of a run in two halves, the second stream waiting
+            # for the first half -- was measured: the launches then alternate perfectly, 1.25 ms apart, and the group's C(t) phase
+            # takes exactly as long as in lockstep: the phase is bound by the kernels' own time, not by coinciding tails.)
+            self.ctx.ct_sums_dev(buf.data_ptr(), self.Npad, self.R, self.F, self.V, bv.psum.data_ptr())
+            if events is not None:
+                events[1].record(main)
+            ct_ev = torch.cuda.Event()
+            ct_ev.record(main)
+            self._ct_done_ev[b] = ct_ev
+        self.ctx.set_stream(self.tail.cuda_stream)
+        with torch.cuda.stream(self.tail):
+            self.tail.wait_event(ct_ev)
+            if j == 0 and grp.guard is not None:
+                self.tail.wait_event(grp.guard)           # a device-side reader of the group's previous C(t)
+            self.ctx.ct_finalize_dev(bv.psum.data_ptr(), self.R, self.F, self.V, bv.Ct.data_ptr(), bv.dCt.data_ptr(),
+                                     bv.CtT.data_ptr(), bv.dCtT.data_ptr())
+            ev = torch.cuda.Event()
+            ev.record(self.tail)
+            self._psum_free[pi] = ev
+            self._last_fin = ev
+        self.ctx.set_stream(self.aux.cuda_stream)
+        with torch.cuda.stream(self.aux):
+            if pack_next is not None:
+                nb = (kk + 1) % self.NB
+                if self._ct_done_ev[nb] is not None:
+                    self.aux.wait_event(self._ct_done_ev[nb])
+                self.stage_pack(pack_next, self.soa_bufs[nb])
+                self._packed_ev[nb] = torch.cuda.Event()
+                self._packed_ev[nb].record(self.aux)
+                self._packed = True
+            if j == 0 and grp.guard is not None:
+                self.aux.wait_event(grp.guard)
+            if events is not None:
+                events[2].record(self.aux)
+            self.stage_hist(bv, buf)
+            if events is not None:
+                events[3].record(self.aux)
+            ev = torch.cuda.Event()
+            ev.record(self.aux)
+            self._last_hist = ev
+        self.ctx.set_stream(self.main.cuda_stream)
+
+    def _back_grouped(self, grp, g, events):
+        st = grp.stream
+        st.wait_event(self._last_fin)        # the tail and auxiliary streams run in order: their last events cover the group
+        st.wait_event(self._last_hist)
+        grp.guard = None
+        v = grp.views(g)
+        n = g * self.V
+        self.ctx.set_stream(st.cuda_stream)
+        with torch.cuda.stream(st):
+            if events is not None and len(events) > 5:
+                events[4].record(st)
+            if not self.dev_skip_fits:
+                self.ctx.order_search_batched_dev(self.t_dev.data_ptr(), 1, grp.CtT.data_ptr(), grp.dCtT.data_ptr(), n, self.L, self.listDoG,
+                                                  self.tau_guess.data_ptr(), 1, self.tau_max, self.chi_thr,
+                                                  v['popt'].data_ptr(), v['dP'].data_ptr(), v['chisq'].data_ptr(), v['status'].data_ptr(),
+                                                  v['nfev'].data_ptr(), v['best'].data_ptr(), v['S2'].data_ptr(), v['C'].data_ptr(),
+                                                  v['tau'].data_ptr(), v['chi'].data_ptr(), v['K'].data_ptr(),
+                                                  work_ptr=grp.fitwork.data_ptr(),
+                                                  dispatch_order_ptr=self._dispatch_order(g).data_ptr() if self.permute else None)
+            if events is not None and len(events) > 5:
+                events[5].record(st)
+            om, fdd, _, tf, gr = self._relax_dev
+            fcsa = self._fcsa_for(g)
+            Kmax = max(self.listDoG) // 2
+            E = len(self.fields)
+            if self.aniso is None or self.aniso == 1.0:
+                self.ctx.relax_dev(1, [self.Diso], E, om.data_ptr(), fdd.data_ptr(), fcsa.data_ptr(), tf.data_ptr(), gr.data_ptr(),
+                                   n, Kmax, self.zeta, v['S2'].data_ptr(), v['C'].data_ptr(), v['tau'].data_ptr(), v['K'].data_ptr(),
+                                   0, None, None, 0, v['relax'].data_ptr())
+            else:
+                Dpar, Dperp = hm.symmtop_from_iso(self.Diso, self.aniso)
+                self.ctx.relax_dev(2, [Dpar, Dperp], E, om.data_ptr(), fdd.data_ptr(), fcsa.data_ptr(), tf.data_ptr(), gr.data_ptr(),
+                                   n, Kmax, self.zeta, v['S2'].data_ptr(), v['C'].data_ptr(), v['tau'].data_ptr(), v['K'].data_ptr(),
+                                   self.nbins, self.binvecs_dev.data_ptr(), grp._hist.data_ptr(), 0, v['relax'].data_ptr())
+            nd, ni = grp._sizes(g)
+            self.ctx.memcpy_d2h_async(grp._h_dres_addr, grp.dres.data_ptr(), nd * 8)
+            self.ctx.memcpy_d2h_async(grp._h_ires_addr, grp.ires.data_ptr(), ni * 4)
+            grp.done = torch.cuda.Event()
+            grp.done.record(st)
+        self._prev_done = grp.done
+        grp.busy = True
+        self.ctx.set_stream(self.main.cuda_stream)
+
+    def collect(self, grp, on_finished=None):
+        grp.done.synchronize()
+        grp.busy = False
+        res = grp.host_results()
+        for j, r in enumerate(res):
+            bv = grp.batches[j]
+            bv.result = r
+            bv.relax_out = r['relax']
+            self.relax_out = r['relax']
+            self.fit_best = r['best']
+            tried = r['status'] != -100
+            self.nfev_total += int(r['nfev'][tried].sum())
+            self.nfev_last = {nP: r['nfev'][i][tried[i]] for i, nP in enumerate(self.listDoG)}
+            if on_finished is not None:
+                on_finished(bv)
+        return res
+
+    def run(self, vecs, nb, events=None, on_finished=None, on_enqueued=None):
+        """nb batches in groups of at most `group`.  on_finished(batch view) per finished batch, in order (batch.result holds its
+        host results, batch.Ct / dCt / hist its device arrays until the group buffer is reused two groups later);
+        on_enqueued(group) right after a group's last launch: a device-side consumer queues itself behind group.done, reads
+        group.Ct / dCt / hist / relax (the g batches in flight) and returns an event the pipeline waits for before it
+        overwrites them.  events[k] as in DevicePipeline.run; [4], [5] are recorded around the merged launch on the entry of
+        the group's FIRST batch."""
+        k, gi = 0, self._nbatch
+        pending = []
+        sizes = list(self.group_sizes(nb))
+        while k < nb:
+            g = sizes.pop(0)
+            grp = self.groups[gi % 2]
+            if grp.busy:
+                pending.remove(grp)
+                self.collect(grp, on_finished)
+            grp.g, grp.first = g, k
+            grp.batches = [grp.batch(j) for j in range(g)]
+            for j in range(g):
+                self._front_grouped(vecs, k + j, grp, j, None if events is None else events[k + j],
+                                    vecs if k + j + 1 < nb else None)
+            self._back_grouped(grp, g, None if events is None else events[k])
+            if on_enqueued is not None:
+                grp.guard = on_enqueued(grp)
+            pending.append(grp)
+            k += g
+            gi += 1
+        for grp in pending:
+            self.collect(grp, on_finished)
+        self._nbatch = gi
+        self.ctx.set_stream(self.main.cuda_stream)
+
+    def prime(self, vecs):
+        """set-up: both group buffers, every stream and code object see a (small) group before the first batch that counts"""
+        for _ in range(2):
+            self.run(vecs, min(self.group, 4))
+        torch.cuda.synchronize(self.dev)
+        self.nfev_total = 0
+
+    def step(self, vecs):
+        self.run(vecs, 1)
+        return self.relax_out
+
+    def close(self):
+        if getattr(self, '_closed', False):
+            return
+        torch.cuda.synchronize(self.dev)
+        self.ctx.device_sync()
+        for grp in self.groups:
+            grp.done = grp.guard = None
+            grp.stream = None
+            grp.batches = []
+            grp.release()
+        self._psum_free = [None] * self.NP
+        self._last_fin = self._last_hist = self._prev_done = None
+        self.tail = None
+        self.slots = self.pool
+        super().close()

@@ -99,6 +99,95 @@ def test_pipeline_batches_in_flight_are_identical_and_ordered(setup, depth, rese
     pipe.close()
 
 
+@pytest.mark.parametrize('group,overlap,nb', [(4, True, 11), (3, False, 7), (8, True, 5), (1, True, 3)])
+def test_grouped_schedule_gives_the_serial_results_for_every_batch(setup, group, overlap, nb):
+    """GroupedPipeline: C(t) / histogram / chunk statistics of a group back to back, then ONE merged model-order search and
+    relaxation launch over the group's residues (dispatched in a permuted order).  Every batch must come out exactly as the
+    serial pipeline gives it -- every array of the result, C(t) and the histogram --, in order, through full groups, the
+    short last group, both group buffers and their reuse."""
+    from spinrelax_amd.pipeline import GroupedPipeline
+    st = setup
+    s, synth = st['s'], st['synth']
+    serial = _pipe(st, 1)
+    serial.step(st['dvecs'])
+    st['torch'].cuda.synchronize()
+    sl = serial.slots[0]
+    want = {k: v.copy() for k, v in sl.result.items()}
+    want_Ct, want_dCt, want_hist = sl.Ct.cpu().numpy(), sl.dCt.cpu().numpy(), sl.hist.cpu().numpy()
+    serial.close()
+    V = st['vecs'].shape[1]
+    pipe = GroupedPipeline(st['ctx'], st['dev'], s['frames'], V, s['R'], s['F'], s['dt'], group=group, overlap=overlap,
+                           q_rot=synth.Q_EXT, Diso=synth.DISO, aniso=synth.DANI, field_MHz=(synth.FIELD_MHZ, 500.0), zeta=synth.ZETA,
+                           stream=st['torch'].cuda.Stream(device=st['dev']))
+    seen, enq = [], []
+
+    def on_finished(b):
+        seen.append((b.index, {k: v.copy() for k, v in b.result.items()}, b.Ct.cpu().numpy(), b.dCt.cpu().numpy(), b.hist.cpu().numpy()))
+
+    def on_enqueued(grp):
+        enq.append((grp.g, tuple(grp.Ct.shape), tuple(grp.relax.shape)))
+        return None
+    for _ in range(2):                        # a second run reuses both group buffers
+        seen.clear()
+        enq.clear()
+        pipe.run(st['dvecs'], nb, None, on_finished, on_enqueued)
+        st['torch'].cuda.synchronize()
+        sizes = [min(group, nb - k) for k in range(0, nb, group)]
+        assert [g for g, *_ in enq] == sizes
+        assert all(cs == (g, s['L'], V) and rs == (2, g * V, 4, 2) for g, cs, rs in enq)
+        assert [i for i, *_ in seen] == [j for g in sizes for j in range(g)]
+        for _, r, Ct, dCt, hist in seen:
+            assert set(r) == set(want)
+            for k in want:
+                assert np.array_equal(r[k], want[k], equal_nan=True), k
+            assert np.array_equal(Ct, want_Ct) and np.array_equal(dCt, want_dCt) and np.array_equal(hist, want_hist)
+    assert pipe.step(st['dvecs']) is not None and np.array_equal(pipe.relax_out, want['relax'], equal_nan=True)
+    pipe.close()
+
+
+def test_batched_order_search_entry_point(setup):
+    """sr_expfit_order_search_batched_f64_dev: a shared time axis (t_rows = 1) and a dispatch permutation change nothing in the
+    results; bad arguments are refused before any launch."""
+    from spinrelax_amd import ct as hostct
+    from spinrelax_amd.hip import SpinRelaxHipError
+    st = setup
+    torch, ctx, s, dev = st['torch'], st['ctx'], st['s'], st['dev']
+    ctx.set_stream(0)
+    serial = _pipe(st, 1)
+    serial.step(st['dvecs'])
+    torch.cuda.synchronize()
+    sl = serial.slots[0]
+    V, L = st['vecs'].shape[1], s['L']
+    nO, Pmax = len(serial.listDoG), max(serial.listDoG)
+    f64, i32 = dict(device=dev, dtype=torch.float64), dict(device=dev, dtype=torch.int32)
+    n = 3 * V
+    y, dy = sl.CtT.repeat(3, 1).contiguous(), sl.dCtT.repeat(3, 1).contiguous()
+    out = dict(popt=torch.empty((nO, n, Pmax), **f64), dP=torch.empty((nO, n, Pmax), **f64), chisq=torch.empty((nO, n), **f64),
+               status=torch.empty((nO, n), **i32), nfev=torch.empty((nO, n), **i32), best=torch.empty((n,), **i32), S2=torch.empty((n,), **f64),
+               C=torch.empty((n, Pmax // 2), **f64), tau=torch.empty((n, Pmax // 2), **f64), chi=torch.empty((n,), **f64), K=torch.empty((n,), **i32))
+    perm = torch.from_numpy(np.random.RandomState(3).permutation(n).astype(np.int32)).to(dev)
+
+    def call(t_rows=1, nRes=n, order=perm):
+        ctx.order_search_batched_dev(serial.t_dev.data_ptr(), t_rows, y.data_ptr(), dy.data_ptr(), nRes, L, serial.listDoG,
+                                     serial.tau_guess.data_ptr(), 1, serial.tau_max, serial.chi_thr,
+                                     out['popt'].data_ptr(), out['dP'].data_ptr(), out['chisq'].data_ptr(), out['status'].data_ptr(),
+                                     out['nfev'].data_ptr(), out['best'].data_ptr(), out['S2'].data_ptr(), out['C'].data_ptr(),
+                                     out['tau'].data_ptr(), out['chi'].data_ptr(), out['K'].data_ptr(),
+                                     dispatch_order_ptr=None if order is None else order.data_ptr())
+        ctx.sync()
+        torch.cuda.synchronize()
+    call()
+    r = sl.result
+    for j in range(3):
+        assert np.array_equal(out['popt'][:, j * V:(j + 1) * V].cpu().numpy(), r['popt'], equal_nan=True)
+        assert np.array_equal(out['nfev'][:, j * V:(j + 1) * V].cpu().numpy(), r['nfev'])
+        assert np.array_equal(out['best'][j * V:(j + 1) * V].cpu().numpy(), r['best'])
+        assert np.array_equal(out['tau'][j * V:(j + 1) * V].cpu().numpy(), r['tau'])
+    with pytest.raises(SpinRelaxHipError):
+        call(t_rows=2)
+    serial.close()
+
+
 def test_pipeline_with_orientation_trajectory(setup):
     """Lab-frame vectors + per-frame orientation quaternions through the pipeline (de-tumbling folded into the pack
     kernel) == the pipeline fed the de-tumbled vectors."""

@@ -12,8 +12,12 @@ model-order search -> J(omega)/R1/R2/NOE/rho, and for N > 1 the RCCL all-gather 
 (SURVEY.md section 8(e)).  Workload: BASELINE.json configs[2] (100 000 frames x 512 vectors, 2 048 lags,
 axisymmetric D, q_ext rotation + vecHistogram) PER GPU -- the configuration the north-star quotes its
 scaling on; weak scaling: every rank owns its own 512 vectors (rank r = vectors 512 r .. 512 r + 511
-of one synthetic trajectory).  `value` = exact triples of all ranks / wall time of a step, with `--depth` batches in
-flight (throughput); `latency_ms` = one batch alone, start to results on the host.
+of one synthetic trajectory).  `value` = exact triples of all ranks / wall time of a step (throughput); `latency_ms` = one
+batch alone, start to results on the host.  Schedule (spinrelax_amd/pipeline.py:GroupedPipeline, `--group`, default 32): the
+C(t) / histogram / chunk-statistics kernels of a group of steps back to back, then ONE merged model-order search and ONE
+relaxation launch over the group's residues; a run of K steps is cut into groups of min(K, 32), every step's work is done
+inside the timed region.  `--group 1` is the per-step schedule of rounds 1-2 (every step launches its own fits, `--depth`
+steps in flight).
 
 One JSON line is printed by rank 0 (contract in the task statement) with extra objects:
   kernels       one entry per kernel of a step, every `frac` a fraction of a bound THAT kernel can reach, from what it
@@ -46,7 +50,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# one hardware queue per in-flight batch (their fit stragglers run ~25 ms each) + the C(t) stream; the HIP runtime
+# one hardware queue per stream the pipeline uses (two C(t) streams, auxiliary, chunk statistics, two group streams, the gather;
+# `--group 1`: one per in-flight batch + the C(t) streams); the HIP runtime
 # multiplexes streams onto 4 queues by default and streams that share a queue serialise (spinrelax_amd/pipeline.py).
 # Not more than needed: two processes with 16 queues each on ONE GPU oversubscribe the hardware queues and the
 # scheduler's time-slicing makes a step 20x slower (seen in the 2-rank rehearsal on one device).
@@ -102,6 +107,7 @@ def parse():
     ap.add_argument('--ct-fft', type=int, default=-1, help='kernel 1: 2 = real-input FFT (k_ct_rfft) where it applies, 1 = complex FFT (k_ct_fft), 0 = direct (k_ct_palmer); -1 = library default (2)')
     ap.add_argument('--ct-traceless', type=int, default=0, help='1: k_ct_rfft<12> with five transforms (traceless components; library option ct_traceless, default off)')
     ap.add_argument('--group', type=int, default=32, help='batches whose fits / relaxation run as ONE merged launch behind their C(t) kernels (GroupedPipeline; a run of K steps uses groups of min(K, group)); 1 = every batch launches its own fits (DevicePipeline, --depth of them in flight)')
+    ap.add_argument('--psum-buffers', type=int, default=3, help='grouped schedule: raw-sum buffers the C(t) launches rotate through')
     ap.add_argument('--no-group-overlap', action='store_true', help='grouped schedule: the next group\'s C(t) kernels wait for the merged fit launch (strict phases)')
     ap.add_argument('--no-permute', action='store_true', help='grouped schedule: dispatch the merged launch in natural residue order')
     ap.add_argument('--depth', type=int, default=5, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
@@ -322,7 +328,7 @@ def main():
     pkw = dict(q_rot=q, Diso=synth.DISO, aniso=aniso, field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA)
     grouped = args.group > 1 and args.depth > 1 and not args.reserve_cus and not args.aux_cus and not args.hist_on_main
     if grouped:
-        pipe = GroupedPipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], group=args.group, overlap=not args.no_group_overlap,
+        pipe = GroupedPipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], group=args.group, overlap=not args.no_group_overlap, psum_buffers=args.psum_buffers,
                                stream=torch.cuda.Stream(device=dev, priority=args.main_priority), plane_buffers=args.plane_buffers, **pkw)
         pipe.permute = not args.no_permute
         pipe.dev_skip_fits = bool(args.dev_skip_fits)
@@ -601,6 +607,11 @@ def main():
                 e['achieved'] = fflop / (tref * 1e-3) / 1e12
                 e['frac'] = e['achieved'] / PEAK_FP64_TFLOPS
                 e['work_note'] = 'executed float64 flop per launch from the PMC pass of the committed profile %s (deterministic data)' % prof_src
+                if fit_ms:
+                    # the launch as it ran inside the timed region: merged over the group, residues in permuted order -- its
+                    # duration includes the tail in which only the last-started expensive residues are still running
+                    e['achieved_in_pipeline'] = fflop * group_used / (fit_ms * 1e-3) / 1e12
+                    e['frac_in_pipeline'] = e['achieved_in_pipeline'] / PEAK_FP64_TFLOPS
             else:
                 e['achieved'] = e['frac'] = None
                 e['work_note'] = 'no committed float64-instruction PMC pass: flop rate not stated'
@@ -622,8 +633,9 @@ def main():
                                           'kernel': kname, 'kernel_ms': ct_ms, 'TFLOPs_equiv': 8.0 * triples / (ct_ms * 1e-3) / 1e12,
                                           'streaming_equiv_GBps': 24.0 * triples / (ct_ms * 1e-3) / 1e9}}
         # what the whole chip does per step: executed float64 work of every kernel of a batch over the step time (the
-        # per-kernel `frac` of an overlapped pipeline is diluted by sharing: two C(t) launches, the fits of three batches, the
-        # pack and the histogram run at the same time, so a launch's own duration says little about the chip)
+        # per-kernel `frac` of an overlapped pipeline is diluted by sharing: two C(t) launches, the pack, the histogram and the
+        # chunk statistics run at the same time -- per-step schedule: the fits of three batches as well --, so a launch's own
+        # duration says little about the chip)
         prof_all, _ = committed_profile()
         step_flop = sum(float(v.get('fp64_flop_per_launch') or 0.0) * (2 if k.startswith('k_transpose') else 1) for k, v in prof_all.items()
                         if not k.startswith('k_fft_init'))

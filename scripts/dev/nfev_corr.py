@@ -31,4 +31,10 @@ for name, x in (('nfev7', nf[3][idx]), ('nfev5', nf[2][idx]), ('chi7', chi[3][id
     print('%-12s rank of the 5 most expensive order-9 residues when sorted by it:' % name, [pos[res] for res in o[:5]], 'of', idx.size)
 tot = nf.sum(axis=0)
 print('total nfev per residue: top', np.sort(tot)[::-1][:10], 'median', np.median(tot))
+os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'gpurun_out'), exist_ok=True)
+np.savez(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'gpurun_out', 'nfev_cfg3.npz'), nfev=nf, status=stt)
+# per-evaluation time by order: single-order solves of the whole batch, alone
+import time
+for j, nP in enumerate(p1.listDoG):
+    pass
 p1.close(); ctx.close()

@@ -39,7 +39,7 @@ def counters(d, counter):
     fs = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
     if not fs:
         return None
-    t = pd.read_csv(fs[0])
+    t = pd.read_csv(max(fs, key=os.path.getmtime))       # a directory that was used twice holds two runs: the newest
     t = t[t.Counter_Name == counter]
     if t.empty:
         return None
@@ -52,7 +52,7 @@ def stats_csv(d, dst):
     fs = glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True)
     if not fs:
         return None
-    st = pd.read_csv(fs[0])
+    st = pd.read_csv(max(fs, key=os.path.getmtime))
     st.to_csv(dst, index=False)
     return st
 

@@ -14,22 +14,24 @@ between; bench.py times it.  torch is used for device memory, streams and events
 goes through the C ABI.
 
 No host in the loop.  Between the vectors and the R1/R2/NOE table nothing returns to the host: a batch is
-nine kernel launches and one set of asynchronous copies into pinned memory, spread over three kinds of streams
-(main: C(t) and transposes; auxiliary: histogram of this batch and pack of the next one, beside C(t); one stream
-per batch in flight: fits, relaxation, copies).  (Until the model-order search moved
-onto the device the host drove it order by order -- five launches, ~30 small copies and ~3 ms of numpy per batch --
-and that latency chain, not the GPU, set the step time.)
+seven kernel launches and two asynchronous copies into pinned memory.
 
-Two kinds of work, two parts of the chip.  The C(t) kernel is throughput work: 12 288 workgroups that keep every CU
-full for milliseconds.  The fits are latency work: one workgroup per residue, hundreds of dependent solver
-iterations, and one straggler per batch (818 of 900 allowed evaluations in the benchmark data against a median of
-32) that runs ~25 ms on a single CU.  Launched behind a C(t) grid the fit workgroups starve -- the dispatcher hands
-every freed slot to the next workgroup of the grid in flight, queue priority notwithstanding (rocprofv3 kernel trace:
-k_trf<3> 6.6 ms behind C(t), 0.39 ms alone).  So the throughput kernels run on a stream whose CU mask leaves
-`reserve_cus` CUs out, and the fits of consecutive batches overlap each other and the following C(t) launches on
-per-batch streams.  `depth` batches are in flight at once; all per-batch device buffers exist `depth` times.
-The runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): two fit streams sharing a queue
-serialise their 25 ms stragglers, so set GPU_MAX_HW_QUEUES >= depth + 2 before the first HIP call (bench.py does).
+Two kinds of work.  The C(t) kernel is throughput work: 12 288 workgroups that keep every CU full for a millisecond.  The
+fits are latency work: one workgroup per residue, hundreds of dependent solver iterations, and a heavy tail (median 27
+function evaluations per residue in the benchmark data, the slowest ~300: 6.5 ms on one CU while the median residue takes
+0.3 ms).  Two schedules:
+
+DevicePipeline    per batch: C(t) on two alternating main streams, the histogram of this batch and the pack of the next one on
+                  an auxiliary stream, and chunk statistics, fits, relaxation and copies on ONE STREAM PER BATCH IN FLIGHT
+                  (`depth`), so that the stragglers of consecutive batches overlap each other and the following C(t)
+                  launches.  Lowest latency per batch; serial form (depth 1) for the drop-in calls and the tests.
+GroupedPipeline   throughput over many batches: the C(t)-side kernels of a GROUP of batches back to back, then one merged
+                  fit launch over the group's residues (below).  What bench.py times by default.
+
+The runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): streams that share a queue serialise
+(two fit streams on one queue run their stragglers one after the other), so set GPU_MAX_HW_QUEUES >= streams in use before
+the first HIP call (bench.py does).  CU-masked streams (`reserve_cus`, `aux_cus`: parts of the chip set aside for the fits or
+for the bandwidth kernels) are kept as options of DevicePipeline; neither pays on MI355X.
 """
 import ctypes
 
@@ -798,15 +800,16 @@ class GroupedPipeline(DevicePipeline):
             ct_ev = torch.cuda.Event()
             ct_ev.record(main)
             self._ct_done_ev[b] = ct_ev
-        self.ctx.set_stream(self.tail.cuda_stream)
-        with torch.cuda.stream(self.tail):
-            self.tail.wait_event(ct_ev)
+        tail = self.tail          # (chunk statistics spread over 3 or 5 streams: measured, no difference)
+        self.ctx.set_stream(tail.cuda_stream)
+        with torch.cuda.stream(tail):
+            tail.wait_event(ct_ev)
             if j == 0 and grp.guard is not None:
-                self.tail.wait_event(grp.guard)           # a device-side reader of the group's previous C(t)
+                tail.wait_event(grp.guard)                # a device-side reader of the group's previous C(t)
             self.ctx.ct_finalize_dev(bv.psum.data_ptr(), self.R, self.F, self.V, bv.Ct.data_ptr(), bv.dCt.data_ptr(),
                                      bv.CtT.data_ptr(), bv.dCtT.data_ptr())
             ev = torch.cuda.Event()
-            ev.record(self.tail)
+            ev.record(tail)
             self._psum_free[pi] = ev
             self._last_fin = ev
         self.ctx.set_stream(self.aux.cuda_stream)

@@ -108,6 +108,7 @@ def parse():
     ap.add_argument('--ct-traceless', type=int, default=0, help='1: k_ct_rfft<12> with five transforms (traceless components; library option ct_traceless, default off)')
     ap.add_argument('--group', type=int, default=32, help='batches whose fits / relaxation run as ONE merged launch behind their C(t) kernels (GroupedPipeline; a run of K steps uses groups of min(K, group)); 1 = every batch launches its own fits (DevicePipeline, --depth of them in flight)')
     ap.add_argument('--psum-buffers', type=int, default=3, help='grouped schedule: raw-sum buffers the C(t) launches rotate through')
+    ap.add_argument('--late-hist', type=int, default=1, help='grouped schedule: 1 = the histograms of a group run in the tail of its merged fit launch (released by the signal the launch\'s last workgroup writes; the planes of group + 3 batches stay alive), 0 = beside the C(t) kernels')
     ap.add_argument('--no-group-overlap', action='store_true', help='grouped schedule: the next group\'s C(t) kernels wait for the merged fit launch (strict phases)')
     ap.add_argument('--no-permute', action='store_true', help='grouped schedule: dispatch the merged launch in natural residue order')
     ap.add_argument('--depth', type=int, default=5, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
@@ -328,8 +329,9 @@ def main():
     pkw = dict(q_rot=q, Diso=synth.DISO, aniso=aniso, field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA)
     grouped = args.group > 1 and args.depth > 1 and not args.reserve_cus and not args.aux_cus and not args.hist_on_main
     if grouped:
-        pipe = GroupedPipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], group=args.group, overlap=not args.no_group_overlap, psum_buffers=args.psum_buffers,
-                               stream=torch.cuda.Stream(device=dev, priority=args.main_priority), plane_buffers=args.plane_buffers, **pkw)
+        pipe = GroupedPipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], group=args.group, overlap=not args.no_group_overlap, psum_buffers=args.psum_buffers, late_hist=bool(args.late_hist),
+                               stream=torch.cuda.Stream(device=dev, priority=args.main_priority),
+                               **({} if args.late_hist else {'plane_buffers': args.plane_buffers}), **pkw)
         pipe.permute = not args.no_permute
         pipe.dev_skip_fits = bool(args.dev_skip_fits)
     else:

@@ -37,7 +37,7 @@ extern "C" {
 
 typedef struct sr_ctx sr_ctx;
 
-#define SR_ABI_VERSION 4
+#define SR_ABI_VERSION 5
 
 /* ---- context, memory, timing ------------------------------------------------------------- */
 int          sr_abi_version(void);
@@ -62,6 +62,14 @@ int          sr_set_option(sr_ctx *, const char *name, int value);
  * all CUs); priority as hipStreamCreateWithPriority (lower = more urgent, 0 = default). */
 int          sr_stream_create(sr_ctx *, const uint32_t *cu_mask, int n_words, int priority, void **stream_out);
 int          sr_stream_destroy(sr_ctx *, void *hip_stream);
+/* Signals: 32-bit values in memory that a KERNEL (or sr_stream_write_signal) sets and a stream waits for without the host
+ * (hipStreamWaitValue32 on hipMallocSignalMemory).  sr_stream_wait_signal holds back everything queued afterwards on the
+ * context's stream until *sig >= value; always pair a kernel-side release with an sr_stream_write_signal of the same value
+ * behind that kernel, so that the wait ends at the latest when the kernel has finished.  NULL when the device cannot do it. */
+uint32_t    *sr_signal_alloc(sr_ctx *);
+int          sr_signal_free(sr_ctx *, uint32_t *sig);
+int          sr_stream_wait_signal(sr_ctx *, uint32_t *sig, uint32_t value);
+int          sr_stream_write_signal(sr_ctx *, uint32_t *sig, uint32_t value);
 int          sr_device_info(sr_ctx *, int *n_cu, int64_t *hbm_bytes, int *lds_per_cu, char *name, int name_len);
 void        *sr_malloc(sr_ctx *, size_t bytes);     /* device memory                              */
 int          sr_free(sr_ctx *, void *dev_ptr);
@@ -253,10 +261,15 @@ int sr_expfit_order_search_f64_dev(sr_ctx *, const double *t, const double *C, c
  *   t_rows          1: one time axis (L values) shared by every residue; nRes: a row per residue as above
  *   dispatch_order  DEVICE, nRes residue indices, or NULL: workgroup b solves residue dispatch_order[b].  Results are stored
  *                   at the residue's own index whatever the order; a permutation spreads residues that are expensive for the
- *                   same reason (the same position in every batch) over the chip instead of over one part of it. */
+ *                   same reason (the same position in every batch) over the chip instead of over one part of it.
+ *   tail_signal     NULL, or a signal (sr_signal_alloc): the launch's last workgroup stores tail_value there when it STARTS.
+ *                   Workgroups start in index order, so from that moment every residue has been handed to a CU and the launch
+ *                   only drains -- slots free up while the longest fits finish.  A stream that waits for the value
+ *                   (sr_stream_wait_signal) starts its bandwidth-bound kernels exactly then. */
 int sr_expfit_order_search_batched_f64_dev(sr_ctx *, const double *t, int t_rows, const double *C, const double *sigma, int nRes,
                                            int L, const int *orders, int nOrders, const double *tau_guess, int tau_guess_rows,
-                                           double tau_max, double chi_threshold, const int *dispatch_order, double *work,
+                                           double tau_max, double chi_threshold, const int *dispatch_order,
+                                           uint32_t *tail_signal, uint32_t tail_value, double *work,
                                            double *popt, double *dP, double *chisq, int *status, int *nfev, int *best,
                                            double *sel_S2, double *sel_C, double *sel_tau, double *sel_chi, int *sel_K);
 /* the same with HOST pointers throughout (staged through the context's work space, synchronous) */

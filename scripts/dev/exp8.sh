@@ -1,0 +1,18 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/exp8
+run() { tag=$1; shift; timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cli-wall --no-kernel-profile "$@" > gpurun_out/exp8/$tag.json 2> gpurun_out/exp8/$tag.err || tail -5 gpurun_out/exp8/$tag.err; python - <<P
+import json
+d=json.load(open('gpurun_out/exp8/$tag.json'))
+k=d['kernels']
+print('$tag', 'step %.3f'%d['ms_per_step'], ['%.2f'%x for x in d['timed_region_samples_ms_per_step']], 'steady %.3f'%d['ms_per_step_steady'], 'inpipe ct %.2f fit %.2f'%(k['k_ct_rfft']['in_pipeline_ms'], k['k_order_search']['in_pipeline_ms']), flush=True)
+P
+}
+run base
+run late --late-hist 1
+export SPINRELAX_HIP_LIB=$PWD/_variants/lib_prio3.so
+run prio3
+run prio3_late --late-hist 1
+unset SPINRELAX_HIP_LIB
+run base2
+export SPINRELAX_HIP_LIB=$PWD/_variants/lib_prio3.so
+run prio3_late2 --late-hist 1

@@ -27,6 +27,10 @@ SIGNATURES = {
     'sr_set_option': (c_int, [c_void_p, c_char_p, c_int]),
     'sr_stream_create': (c_int, [c_void_p, POINTER(ctypes.c_uint32), c_int, c_int, POINTER(c_void_p)]),
     'sr_stream_destroy': (c_int, [c_void_p, c_void_p]),
+    'sr_signal_alloc': (c_void_p, [c_void_p]),
+    'sr_signal_free': (c_int, [c_void_p, c_void_p]),
+    'sr_stream_wait_signal': (c_int, [c_void_p, c_void_p, ctypes.c_uint32]),
+    'sr_stream_write_signal': (c_int, [c_void_p, c_void_p, ctypes.c_uint32]),
     'sr_device_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int64), POINTER(c_int), c_char_p, c_int]),
     'sr_malloc': (c_void_p, [c_void_p, c_size_t]),
     'sr_free': (c_int, [c_void_p, c_void_p]),
@@ -70,7 +74,8 @@ SIGNATURES = {
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     # (ctx, t, t_rows, C, sigma, nRes, L, orders, nOrders, tau_guess, tau_rows, tau_max, chi_thr, dispatch_order, work, popt, ...)
     'sr_expfit_order_search_batched_f64_dev': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
-                                                       c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                       c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, ctypes.c_uint32,
+                                                       c_void_p, c_void_p, c_void_p,
                                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                        c_void_p]),
     'sr_expfit_order_search_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
@@ -117,7 +122,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 LIB_PATH = os.environ.get('SPINRELAX_HIP_LIB', LIB_PATH)      # alternative build of the same ABI
 
 

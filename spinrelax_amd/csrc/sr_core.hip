@@ -185,6 +185,48 @@ int sr_stream_destroy(sr_ctx *ctx, void *hip_stream)
     return 0;
 }
 
+// ---- signals: a stream waits for a value that a KERNEL writes (hipStreamWaitValue32 on signal memory) ----
+uint32_t *sr_signal_alloc(sr_ctx *ctx)
+{
+    if (!ctx) { sr_set_error("sr_signal_alloc: NULL context"); return nullptr; }
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, ctx->device) != hipSuccess || !can) {
+        sr_set_error("sr_signal_alloc: the device cannot wait on memory values from a stream");
+        return nullptr;
+    }
+    uint32_t *p = nullptr;
+    if (hipExtMallocWithFlags((void **)&p, 8, hipMallocSignalMemory) != hipSuccess || !p) {
+        sr_set_error("sr_signal_alloc: hipExtMallocWithFlags(hipMallocSignalMemory) failed");
+        return nullptr;
+    }
+    p[0] = 0u;
+    p[1] = 0u;
+    return p;
+}
+
+int sr_signal_free(sr_ctx *ctx, uint32_t *sig)
+{
+    SR_CHECK_CTX(ctx);
+    if (sig) SR_HIP(hipFree(sig));
+    return 0;
+}
+
+int sr_stream_wait_signal(sr_ctx *ctx, uint32_t *sig, uint32_t value)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(sig != nullptr, -2, "sr_stream_wait_signal: NULL signal");
+    SR_HIP(hipStreamWaitValue32(ctx->stream, sig, value, hipStreamWaitValueGte, 0xFFFFFFFFu));
+    return 0;
+}
+
+int sr_stream_write_signal(sr_ctx *ctx, uint32_t *sig, uint32_t value)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(sig != nullptr, -2, "sr_stream_write_signal: NULL signal");
+    SR_HIP(hipStreamWriteValue32(ctx->stream, sig, value, 0));
+    return 0;
+}
+
 int sr_sync(sr_ctx *ctx)
 {
     SR_CHECK_CTX(ctx);

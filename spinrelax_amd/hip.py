@@ -372,15 +372,32 @@ class Context:
                                                       popt_ptr, dP_ptr, chisq_ptr, status_ptr, nfev_ptr, best_ptr, S2_ptr, C_ptr,
                                                       tau_ptr, chi_ptr, K_ptr), 'sr_expfit_order_search_f64_dev')
 
+    # ---- signals (a stream waits for a value a kernel writes) ----
+    def signal_alloc(self):
+        p = self.lib.sr_signal_alloc(self.h)
+        if not p:
+            raise SpinRelaxHipError('sr_signal_alloc failed: %s' % _lib.last_error())
+        return p
+
+    def signal_free(self, sig):
+        check(self.lib.sr_signal_free(self.h, sig), 'sr_signal_free')
+
+    def stream_wait_signal(self, sig, value):
+        check(self.lib.sr_stream_wait_signal(self.h, sig, int(value)), 'sr_stream_wait_signal')
+
+    def stream_write_signal(self, sig, value):
+        check(self.lib.sr_stream_write_signal(self.h, sig, int(value)), 'sr_stream_write_signal')
+
     def order_search_batched_dev(self, t_ptr, t_rows, y_ptr, sigma_ptr, nRes, L, orders, tau_guess_ptr, tau_rows, tau_max, chi_threshold,
                                  popt_ptr, dP_ptr, chisq_ptr, status_ptr, nfev_ptr, best_ptr, S2_ptr, C_ptr, tau_ptr, chi_ptr, K_ptr,
-                                 work_ptr=None, dispatch_order_ptr=None):
+                                 work_ptr=None, dispatch_order_ptr=None, tail_signal=None, tail_value=0):
         """the model-order search of several batches' residues in one launch (sr_expfit_order_search_batched_f64_dev):
         t_rows = 1 shares one time axis, dispatch_order (device int32, nRes) permutes the order in which residues start"""
         orders = np.ascontiguousarray(orders, dtype=np.int32)
         check(self.lib.sr_expfit_order_search_batched_f64_dev(self.h, t_ptr, t_rows, y_ptr, sigma_ptr, nRes, L, _ptr(orders), orders.size,
                                                               tau_guess_ptr, tau_rows, float(tau_max), float(chi_threshold),
-                                                              dispatch_order_ptr, work_ptr, popt_ptr, dP_ptr, chisq_ptr, status_ptr,
+                                                              dispatch_order_ptr, tail_signal, int(tail_value), work_ptr, popt_ptr, dP_ptr,
+                                                              chisq_ptr, status_ptr,
                                                               nfev_ptr, best_ptr, S2_ptr, C_ptr, tau_ptr, chi_ptr, K_ptr),
               'sr_expfit_order_search_batched_f64_dev')
 

@@ -687,7 +687,10 @@ class GroupedPipeline(DevicePipeline):
                 kernels beside them) -- no fit is in flight, so the C(t) grids have the chip's registers to themselves
                 and the pack / histogram waves find slots beside them;
       phase 2   ONE model-order search over the group's g x V residues (sr_expfit_order_search_batched_f64_dev), one
-                relaxation launch, one pair of copies to pinned memory.
+                relaxation launch, one pair of copies to pinned memory; with `late_hist` (default) the group's histograms
+                run HERE, in the tail of the merged launch: its last workgroup releases a signal the histogram stream waits
+                for (every residue has a CU by then; only the longest fits are still running and most slots are free), so
+                that phase 1 is C(t) + pack + chunk statistics only.  The planes of group + 3 batches stay alive for that.
 
     Why: a fit launch lasts as long as its slowest residue (one nine-parameter fit that never converges: ~300 evaluations,
     6.5 ms) while the median residue needs 0.3 ms.  Launched per batch, the stragglers of ~3 batches are always in flight
@@ -702,9 +705,12 @@ class GroupedPipeline(DevicePipeline):
     The next group's phase 1 is queued behind the merged launch without waiting for it (`overlap`), so the tail of one
     group's stragglers is covered by the next group's C(t) kernels; two group buffers alternate."""
 
-    def __init__(self, ctx, device, frames, V, R, F, dt, group=32, overlap=True, psum_buffers=3, **kw):
+    def __init__(self, ctx, device, frames, V, R, F, dt, group=32, overlap=True, psum_buffers=3, late_hist=True, **kw):
         kw = dict(kw)
         kw['depth'] = max(2, int(psum_buffers))          # the base class's slots: only their raw-sum buffers are used (a rotating pool)
+        self.late_hist = bool(late_hist)
+        if self.late_hist:
+            kw['plane_buffers'] = max(1, int(group)) + 3       # a group's planes stay alive until its histograms ran (in phase 2)
         for name in ('reserve_cus', 'aux_cus'):
             if kw.get(name):
                 raise ValueError('GroupedPipeline runs its phases on the whole chip: %s is not supported' % name)
@@ -713,6 +719,8 @@ class GroupedPipeline(DevicePipeline):
         self.overlap = bool(overlap)
         self.permute = True            # dispatch the merged launch's residues in a fixed pseudo-random order
         self.dev_skip_fits = False     # development only
+        import os as _os
+        self.dev_skip_hist = bool(_os.environ.get('SR_DEV_SKIP_HIST'))      # development only: marginal cost of the histogram in phase 1
         self.pool = self.slots
         self.NP = len(self.pool)
         self._psum_free = [None] * self.NP
@@ -721,6 +729,12 @@ class GroupedPipeline(DevicePipeline):
         E = len(self.fields)
         self.groups = [_Group(ctx, device, self.group, V, self.L, R, self.nbins, len(self.listDoG), Pmax, E,
                               torch.cuda.Stream(device=device)) for _ in range(2)]
+        self.hist_stream = torch.cuda.Stream(device=device) if self.late_hist else None
+        self._late = []
+        self._hist_done_ev = [None] * self.NB           # late histograms: "the histogram that read this plane buffer has run"
+        if self.late_hist:
+            for grp in self.groups:
+                grp.signal, grp.epoch = ctx.signal_alloc(), 0
         self.slots = self.groups                          # what a caller iterates over to set up per-slot consumers
         self._perm = {}
         self._fcsa = {}
@@ -777,6 +791,8 @@ class GroupedPipeline(DevicePipeline):
             with torch.cuda.stream(self.aux):
                 if self._ct_done_ev[b] is not None:
                     self.aux.wait_event(self._ct_done_ev[b])
+                if self._hist_done_ev[b] is not None:
+                    self.aux.wait_event(self._hist_done_ev[b])
                 self.stage_pack(vecs, buf)
                 self._packed_ev[b] = torch.cuda.Event()
                 self._packed_ev[b].record(self.aux)
@@ -818,16 +834,21 @@ class GroupedPipeline(DevicePipeline):
                 nb = (kk + 1) % self.NB
                 if self._ct_done_ev[nb] is not None:
                     self.aux.wait_event(self._ct_done_ev[nb])
+                if self._hist_done_ev[nb] is not None:
+                    self.aux.wait_event(self._hist_done_ev[nb])
                 self.stage_pack(pack_next, self.soa_bufs[nb])
                 self._packed_ev[nb] = torch.cuda.Event()
                 self._packed_ev[nb].record(self.aux)
                 self._packed = True
             if j == 0 and grp.guard is not None:
                 self.aux.wait_event(grp.guard)
-            if events is not None:
+            if events is not None and not self.late_hist:
                 events[2].record(self.aux)
-            self.stage_hist(bv, buf)
-            if events is not None:
+            if self.late_hist:
+                self._late.append((bv, buf, b, events))
+            elif not self.dev_skip_hist:
+                self.stage_hist(bv, buf)
+            if events is not None and not self.late_hist:
                 events[3].record(self.aux)
             ev = torch.cuda.Event()
             ev.record(self.aux)
@@ -838,6 +859,7 @@ class GroupedPipeline(DevicePipeline):
         st = grp.stream
         st.wait_event(self._last_fin)        # the tail and auxiliary streams run in order: their last events cover the group
         st.wait_event(self._last_hist)
+        grp.guard_hist = grp.guard if self.late_hist else None
         grp.guard = None
         v = grp.views(g)
         n = g * self.V
@@ -852,9 +874,40 @@ class GroupedPipeline(DevicePipeline):
                                                   v['nfev'].data_ptr(), v['best'].data_ptr(), v['S2'].data_ptr(), v['C'].data_ptr(),
                                                   v['tau'].data_ptr(), v['chi'].data_ptr(), v['K'].data_ptr(),
                                                   work_ptr=grp.fitwork.data_ptr(),
-                                                  dispatch_order_ptr=self._dispatch_order(g).data_ptr() if self.permute else None)
+                                                  dispatch_order_ptr=self._dispatch_order(g).data_ptr() if self.permute else None,
+                                                  tail_signal=grp.signal if self.late_hist else None,
+                                                  tail_value=grp.epoch + 1 if self.late_hist else 0)
             if events is not None and len(events) > 5:
                 events[5].record(st)
+            if self.late_hist:
+                # The group's histograms fill the TAIL of the merged launch.  Its last workgroup releases the signal when it
+                # starts (every residue has a CU by then; from here on slots only free up while the longest fits finish); the
+                # histogram stream has been waiting for exactly that.  The write behind the launch releases it at the latest
+                # when the launch is over (skipped fits, a launch that fits the chip at once).
+                grp.epoch += 1
+                self.ctx.stream_write_signal(grp.signal, grp.epoch)
+                hs = self.hist_stream
+                hs.wait_event(self._last_hist)            # every pack of the group has run (auxiliary stream, in order)
+                if grp.guard_hist is not None:
+                    hs.wait_event(grp.guard_hist)
+                    grp.guard_hist = None
+                self.ctx.set_stream(hs.cuda_stream)
+                with torch.cuda.stream(hs):
+                    self.ctx.stream_wait_signal(grp.signal, grp.epoch)
+                    for bv, buf, b, evs in self._late:
+                        if evs is not None:
+                            evs[2].record(hs)
+                        self.stage_hist(bv, buf)
+                        if evs is not None:
+                            evs[3].record(hs)
+                        ev = torch.cuda.Event()
+                        ev.record(hs)
+                        self._hist_done_ev[b] = ev
+                    hev = torch.cuda.Event()
+                    hev.record(hs)
+                self._late = []
+                self.ctx.set_stream(st.cuda_stream)
+                st.wait_event(hev)
             om, fdd, _, tf, gr = self._relax_dev
             fcsa = self._fcsa_for(g)
             Kmax = max(self.listDoG) // 2
@@ -946,7 +999,12 @@ class GroupedPipeline(DevicePipeline):
             grp.done = grp.guard = None
             grp.stream = None
             grp.batches = []
+            if getattr(grp, 'signal', None):
+                self.ctx.signal_free(grp.signal)
+                grp.signal = None
             grp.release()
+        self.hist_stream = None
+        self._hist_done_ev = []
         self._psum_free = [None] * self.NP
         self._last_fin = self._last_hist = self._prev_done = None
         self.tail = None

@@ -99,12 +99,14 @@ def test_pipeline_batches_in_flight_are_identical_and_ordered(setup, depth, rese
     pipe.close()
 
 
-@pytest.mark.parametrize('group,overlap,nb', [(4, True, 11), (3, False, 7), (8, True, 5), (1, True, 3)])
-def test_grouped_schedule_gives_the_serial_results_for_every_batch(setup, group, overlap, nb):
+@pytest.mark.parametrize('group,overlap,nb,late', [(4, True, 11, False), (3, False, 7, False), (8, True, 5, False), (1, True, 3, False),
+                                                    (4, True, 11, True), (3, False, 7, True), (8, True, 5, True)])
+def test_grouped_schedule_gives_the_serial_results_for_every_batch(setup, group, overlap, nb, late):
     """GroupedPipeline: C(t) / histogram / chunk statistics of a group back to back, then ONE merged model-order search and
     relaxation launch over the group's residues (dispatched in a permuted order).  Every batch must come out exactly as the
     serial pipeline gives it -- every array of the result, C(t) and the histogram --, in order, through full groups, the
-    short last group, both group buffers and their reuse."""
+    short last group, both group buffers and their reuse.  late: the group's histograms run behind the merged launch, released
+    by the signal its last workgroup writes (sr_signal_alloc / sr_stream_wait_signal)."""
     from spinrelax_amd.pipeline import GroupedPipeline
     st = setup
     s, synth = st['s'], st['synth']
@@ -116,7 +118,7 @@ def test_grouped_schedule_gives_the_serial_results_for_every_batch(setup, group,
     want_Ct, want_dCt, want_hist = sl.Ct.cpu().numpy(), sl.dCt.cpu().numpy(), sl.hist.cpu().numpy()
     serial.close()
     V = st['vecs'].shape[1]
-    pipe = GroupedPipeline(st['ctx'], st['dev'], s['frames'], V, s['R'], s['F'], s['dt'], group=group, overlap=overlap,
+    pipe = GroupedPipeline(st['ctx'], st['dev'], s['frames'], V, s['R'], s['F'], s['dt'], group=group, overlap=overlap, late_hist=late,
                            q_rot=synth.Q_EXT, Diso=synth.DISO, aniso=synth.DANI, field_MHz=(synth.FIELD_MHZ, 500.0), zeta=synth.ZETA,
                            stream=st['torch'].cuda.Stream(device=st['dev']))
     seen, enq = [], []

@@ -190,6 +190,44 @@ def test_batched_order_search_entry_point(setup):
     serial.close()
 
 
+def test_signals_release_a_waiting_stream(setup):
+    """sr_signal_alloc / sr_stream_write_signal / sr_stream_wait_signal: work queued behind a wait runs once the value is there
+    (written by another stream here; by the merged fit launch's last workgroup in GroupedPipeline), a value already reached does
+    not block, NULL signals are refused."""
+    from spinrelax_amd.hip import SpinRelaxHipError
+    st = setup
+    torch, ctx, dev = st['torch'], st['ctx'], st['dev']
+    sig = ctx.signal_alloc()
+    a, b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    x = torch.zeros(1 << 20, device=dev)
+    torch.cuda.synchronize()
+    ctx.set_stream(b.cuda_stream)
+    ctx.stream_wait_signal(sig, 1)
+    with torch.cuda.stream(b):
+        x.add_(1.0)
+        done = torch.cuda.Event()
+        done.record(b)
+    import time
+    time.sleep(0.05)
+    assert not done.query()                      # parked on the signal
+    ctx.set_stream(a.cuda_stream)
+    ctx.stream_write_signal(sig, 1)
+    done.synchronize()
+    assert float(x.sum().item()) == float(1 << 20)
+    ctx.set_stream(b.cuda_stream)
+    ctx.stream_wait_signal(sig, 1)               # already reached (>=): passes
+    with torch.cuda.stream(b):
+        x.add_(1.0)
+    torch.cuda.synchronize()
+    assert float(x[0].item()) == 2.0
+    with pytest.raises(SpinRelaxHipError):
+        ctx.stream_wait_signal(None, 1)
+    with pytest.raises(SpinRelaxHipError):
+        ctx.stream_write_signal(None, 1)
+    ctx.set_stream(0)
+    ctx.signal_free(sig)
+
+
 def test_pipeline_with_orientation_trajectory(setup):
     """Lab-frame vectors + per-frame orientation quaternions through the pipeline (de-tumbling folded into the pack
     kernel) == the pipeline fed the de-tumbled vectors."""

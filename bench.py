@@ -354,13 +354,27 @@ def main():
         gstream = torch.cuda.Stream(device=dev) if world > 1 else None
         gbuf = {}
 
+        def gather_part(kind, bv, ev):
+            """grouped schedule: the bulky per-batch arrays travel as soon as they are final (C(t), dC(t) behind the batch's chunk
+            statistics; the histogram behind its kernel), beside the rest of the group's work -- not in one piece at its end"""
+            if world == 1:
+                return
+            with torch.cuda.stream(gstream):
+                gstream.wait_event(ev)
+                for name in (('Ct', 'dCt') if kind == 'ct' else ('hist',)):
+                    tns = getattr(bv, name)
+                    key = ('part', name, tuple(tns.shape))
+                    if key not in gbuf:
+                        gbuf[key] = [torch.empty_like(tns) for _ in range(world)]
+                    dist.all_gather(gbuf[key], tns)
+
         def gather_results(slot):
             """queued right behind a batch (pipeline.run(on_enqueued=...)): waits for the batch on the device, never on the host"""
             if world == 1:
                 return None
             with torch.cuda.stream(gstream):
                 gstream.wait_event(slot.done)
-                for name in ('Ct', 'dCt', 'hist', 'relax'):          # a slot is one batch (DevicePipeline) or a group of them
+                for name in (('relax',) if grouped else ('Ct', 'dCt', 'hist', 'relax')):   # grouped: the rest went through gather_part
                     tns = getattr(slot, name)
                     key = (id(slot), name, tuple(tns.shape))
                     if key not in gbuf:
@@ -371,7 +385,10 @@ def main():
             return ev
 
         def run_batches(nb, events=None):
-            pipe.run(vecs, nb, events, on_enqueued=gather_results)
+            if grouped:
+                pipe.run(vecs, nb, events, on_enqueued=gather_results, on_part=gather_part)
+            else:
+                pipe.run(vecs, nb, events, on_enqueued=gather_results)
             torch.cuda.synchronize()
 
         pipe.prime(vecs)                 # set-up (code objects, first touch of every in-flight slot), not a warm-up step

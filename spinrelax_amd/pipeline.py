@@ -740,6 +740,7 @@ class GroupedPipeline(DevicePipeline):
         self.slots = self.groups                          # what a caller iterates over to set up per-slot consumers
         self._perm = {}
         self._fcsa = {}
+        self._on_part = None
         self._last_fin = None
         self._last_hist = None
         self._prev_done = None
@@ -831,6 +832,8 @@ class GroupedPipeline(DevicePipeline):
             ev.record(tail)
             self._psum_free[pi] = ev
             self._last_fin = ev
+            if self._on_part is not None:
+                self._on_part('ct', bv, ev)          # C(t), dC(t) of this batch are final once `ev` has passed
         self.ctx.set_stream(self.aux.cuda_stream)
         with torch.cuda.stream(self.aux):
             if pack_next is not None:
@@ -856,6 +859,8 @@ class GroupedPipeline(DevicePipeline):
             ev = torch.cuda.Event()
             ev.record(self.aux)
             self._last_hist = ev
+            if self._on_part is not None and not self.late_hist:
+                self._on_part('hist', bv, ev)
         self.ctx.set_stream(self.main.cuda_stream)
 
     def _back_grouped(self, grp, g, events):
@@ -905,6 +910,8 @@ class GroupedPipeline(DevicePipeline):
                         ev = torch.cuda.Event()
                         ev.record(hs)
                         self._hist_done_ev[b] = ev
+                        if self._on_part is not None:
+                            self._on_part('hist', bv, ev)
                     hev = torch.cuda.Event()
                     hev.record(hs)
                 self._late = []
@@ -949,13 +956,17 @@ class GroupedPipeline(DevicePipeline):
                 on_finished(bv)
         return res
 
-    def run(self, vecs, nb, events=None, on_finished=None, on_enqueued=None):
+    def run(self, vecs, nb, events=None, on_finished=None, on_enqueued=None, on_part=None):
         """nb batches in groups of at most `group`.  on_finished(batch view) per finished batch, in order (batch.result holds its
         host results, batch.Ct / dCt / hist its device arrays until the group buffer is reused two groups later);
         on_enqueued(group) right after a group's last launch: a device-side consumer queues itself behind group.done, reads
         group.Ct / dCt / hist / relax (the g batches in flight) and returns an event the pipeline waits for before it
-        overwrites them.  events[k] as in DevicePipeline.run; [4], [5] are recorded around the merged launch on the entry of
-        the group's FIRST batch."""
+        overwrites them.  on_part(kind, batch view, event): called when the launch that finishes one batch's C(t) / dC(t)
+        (kind 'ct') or histogram ('hist') has been queued; `event` marks its completion -- a device-side consumer can move the
+        bulky per-batch arrays while the group is still being computed and leave only the small table for on_enqueued (whose
+        returned event must cover everything the consumer read of the group).  events[k] as in DevicePipeline.run; [4], [5] are
+        recorded around the merged launch on the entry of the group's FIRST batch."""
+        self._on_part = on_part
         k, gi = 0, self._nbatch
         pending = []
         sizes = list(self.group_sizes(nb))
@@ -978,6 +989,7 @@ class GroupedPipeline(DevicePipeline):
             gi += 1
         for grp in pending:
             self.collect(grp, on_finished)
+        self._on_part = None
         self._nbatch = gi
         self.ctx.set_stream(self.main.cuda_stream)
 

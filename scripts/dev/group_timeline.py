@@ -22,6 +22,7 @@ pipe = GroupedPipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], group=
                        field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA, stream=torch.cuda.Stream(device=dev))
 if len(sys.argv) > 4:
     pipe.sizes_override = [int(x) for x in sys.argv[4].split(',')]
+pipe.gate_next = bool(os.environ.get('GATE'))
 pipe.prime(vecs)
 for _ in range(6):
     pipe.run(vecs, K)

@@ -734,9 +734,13 @@ class GroupedPipeline(DevicePipeline):
         self._hist_done_ev = [None] * self.NB           # late histograms: "the histogram that read this plane buffer has run"
         for grp in self.groups:
             grp.signal, grp.epoch = ctx.signal_alloc(), 0
-        # (Holding the next group's C(t) launches back with the same signal until the merged launch begins to drain was measured:
-        # 2.13 against 2.115 ms per step in steady state -- queued behind a launch that fills the chip they hardly get a slot
-        # before that moment anyway.)
+        # gate_next: hold the next group's C(t) launches back (same signal) until the merged launch begins to drain.  Measured, off:
+        # 2.13 against 2.115 ms per step in steady state (queued behind a launch that fills the chip they hardly get a slot before
+        # that moment anyway), and no help to unequal splits of a 20-batch run (16 + 4, 14 + 6, ...: 49-51 ms like one group of
+        # 20) -- when the last workgroup starts, the 512 resident ones are the long-lived ones and free their slots over
+        # milliseconds, so C(t) grids released at that moment run at a fraction of their speed (4 launches: 9 ms).
+        self.gate_next = False
+        self._prev_signal = None
         self.slots = self.groups                          # what a caller iterates over to set up per-slot consumers
         self._perm = {}
         self._fcsa = {}
@@ -808,6 +812,8 @@ class GroupedPipeline(DevicePipeline):
                 main.wait_event(self._psum_free[pi])      # the chunk statistics of batch kk - NP have read these raw sums
             if j < 2 and not self.overlap and self._prev_done is not None:
                 main.wait_event(self._prev_done)          # strict phases: the previous group's merged launch has finished (both C(t) streams)
+            elif j < 2 and self.gate_next and self._prev_signal is not None:
+                self.ctx.stream_wait_signal(*self._prev_signal)
 
             if events is not None:
                 events[0].record(main)
@@ -888,6 +894,7 @@ class GroupedPipeline(DevicePipeline):
                 events[5].record(st)
             grp.epoch += 1
             self.ctx.stream_write_signal(grp.signal, grp.epoch)
+            self._prev_signal = (grp.signal, grp.epoch)
             if self.late_hist:
                 # The group's histograms fill the TAIL of the merged launch.  Its last workgroup releases the signal when it
                 # starts (every residue has a CU by then; from here on slots only free up while the longest fits finish); the

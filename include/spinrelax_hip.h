@@ -37,7 +37,7 @@ extern "C" {
 
 typedef struct sr_ctx sr_ctx;
 
-#define SR_ABI_VERSION 5
+#define SR_ABI_VERSION 6
 
 /* ---- context, memory, timing ------------------------------------------------------------- */
 int          sr_abi_version(void);
@@ -381,6 +381,28 @@ int sr_dq_moments_f64(sr_ctx *, const double *q, int64_t N, const int32_t *lags,
  * out[c*rows + r] = in[r*cols + c] (float64, device pointers): C(t) leaves kernel 1 as (lags, vectors)
  * like the reference, the fit reads (residues, lags). */
 int sr_transpose_f64_dev(sr_ctx *, const double *in, int64_t rows, int64_t cols, double *out);
+
+/* ---- host-side text I/O of the reference's xmgrace-style files (no device work) ----------------------------------
+ * run-all.bash passes C(t) between its scripts as text: `<prefix>_Ctint.dat` is written by print_sxylist
+ * (general_scripts.py:275-290) and read back by load_sxydylist (:182-213); `_fittedCt.dat` carries "%8g %8g" rows
+ * (fitting_Ct_functions.py:107-126).  For 512 residues x 2 048 lags that is 31 + 38 MB of text per run, and with the kernels
+ * at milliseconds its formatting / parsing in Python was 90 % of the chain's wall time.  These entry points produce exactly
+ * the bytes / doubles of the Python code (numpy's array printer for the (C, dC) pairs, strtod for reading); a positive
+ * return code (or `regular` = 0) means "not the regular case -- use the Python path" and nothing has been written.
+ *   sr_text_write_sxydy_f64   legend_lines / xstr: nsets / npts strings separated by '\0'; ydy (nsets, npts, 2)
+ *   sr_text_format_g8_pairs   n rows "%8g %8g\n" into out (>= 32 n bytes); returns the bytes written; offsets[k] = byte position
+ *                             of row bounds[k] (optional: where the caller cuts the text into blocks)
+ *   sr_text_open_sxydy        parse a file; info6 = {regular, nsets, npts, has_dy, legends, bytes of the '\0'-joined legends};
+ *                             sr_text_sxydy_get copies x, y, dy (nsets, npts) and the legends out; sr_text_close_sxydy frees */
+typedef struct sr_sxydy sr_sxydy;
+int       sr_text_write_sxydy_f64(const char *path, const char *header, int64_t nsets, int64_t npts, const char *legend_lines,
+                                  const char *xstr, const double *ydy, int nthreads);
+int64_t   sr_text_format_g8_pairs(const double *a, const double *b, int64_t n, char *out, int64_t out_bytes, int nthreads,
+                                  const int64_t *bounds, int64_t nb, int64_t *offsets);
+sr_sxydy *sr_text_open_sxydy(const char *path, const char *key, int nthreads);
+void      sr_text_close_sxydy(sr_sxydy *);
+int       sr_text_sxydy_info(const sr_sxydy *, int64_t *info6);
+int       sr_text_sxydy_get(const sr_sxydy *, double *x, double *y, double *dy, char *legends);
 
 #ifdef __cplusplus
 }

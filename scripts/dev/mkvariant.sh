@@ -8,7 +8,7 @@ root=$(cd $(dirname $0)/../.. && pwd)
 c=$root/spinrelax_amd/csrc
 mkdir -p $root/_variants/obj_$name
 objs=""
-for src in sr_core sr_ct sr_vechist sr_fit sr_relax sr_dq sr_traj sr_vectors; do
+for src in sr_core sr_ct sr_vechist sr_fit sr_relax sr_dq sr_traj sr_vectors sr_textio; do
   o=$c/$src.o
   for f in "$@"; do
     if [ "$f" = "$src.hip" ]; then

@@ -27,6 +27,12 @@ SIGNATURES = {
     'sr_set_option': (c_int, [c_void_p, c_char_p, c_int]),
     'sr_stream_create': (c_int, [c_void_p, POINTER(ctypes.c_uint32), c_int, c_int, POINTER(c_void_p)]),
     'sr_stream_destroy': (c_int, [c_void_p, c_void_p]),
+    'sr_text_write_sxydy_f64': (c_int, [c_char_p, c_char_p, c_int64, c_int64, c_char_p, c_char_p, c_void_p, c_int]),
+    'sr_text_format_g8_pairs': (c_int64, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    'sr_text_open_sxydy': (c_void_p, [c_char_p, c_char_p, c_int]),
+    'sr_text_close_sxydy': (None, [c_void_p]),
+    'sr_text_sxydy_info': (c_int, [c_void_p, c_void_p]),
+    'sr_text_sxydy_get': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'sr_signal_alloc': (c_void_p, [c_void_p]),
     'sr_signal_free': (c_int, [c_void_p, c_void_p]),
     'sr_stream_wait_signal': (c_int, [c_void_p, c_void_p, ctypes.c_uint32]),
@@ -122,7 +128,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 5
+ABI_VERSION = 6
 LIB_PATH = os.environ.get('SPINRELAX_HIP_LIB', LIB_PATH)      # alternative build of the same ABI
 
 

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libspinrelax_hip.so')
-SOURCES = ['sr_core.hip', 'sr_ct.hip', 'sr_vechist.hip', 'sr_fit.hip', 'sr_relax.hip', 'sr_dq.hip', 'sr_traj.hip', 'sr_vectors.hip']
+SOURCES = ['sr_core.hip', 'sr_ct.hip', 'sr_vechist.hip', 'sr_fit.hip', 'sr_relax.hip', 'sr_dq.hip', 'sr_traj.hip', 'sr_vectors.hip', 'sr_textio.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 # sr_ct.hip: the SLP vectoriser packs the FMAs of the C(t) inner loop into v_pk_fma_f32, whose operand pairs then

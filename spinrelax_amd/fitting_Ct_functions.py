@@ -332,19 +332,46 @@ class autoCorrelations:
 
     def export(self, fileName, style='xmgrace'):
         """fitting_Ct_functions.py:107-126: header block, fitted curve, raw curve per residue."""
+        from .general_scripts import _native_lib
+        lib = _native_lib()
+        keys = list(self.model.keys())
+        curves = [self.model[k].eval(self.DeltaT[k]) for k in keys]
+        # every "%8g %8g" row of the file in ONE threaded call of the library (same C formatting), cut at the block boundaries
+        blocks = None
+        if lib is not None and keys:
+            A = np.concatenate([np.concatenate((np.asarray(self.DeltaT[k], dtype=np.float64)[:len(c)],) * 2) for k, c in zip(keys, curves)])
+            B = np.concatenate([np.concatenate((np.asarray(c, dtype=np.float64), np.asarray(self.Decay[k], dtype=np.float64)[:len(c)]))
+                                for k, c in zip(keys, curves)])
+            if np.isfinite(A).all() and np.isfinite(B).all():
+                import ctypes
+                bounds = np.cumsum([0] + [len(c) for c in curves for _ in (0, 1)]).astype(np.int64)
+                offs = np.empty(bounds.size, dtype=np.int64)
+                buf = ctypes.create_string_buffer(32 * max(1, A.size))
+                n = lib.sr_text_format_g8_pairs(A.ctypes.data, B.ctypes.data, A.size, buf, 32 * A.size, 0, bounds.ctypes.data, bounds.size,
+                                                offs.ctypes.data)
+                if n >= 0:
+                    text = buf.raw[:n].decode('ascii')
+                    blocks = [text[offs[i]:offs[i + 1]] for i in range(bounds.size - 1)]
         with open(fileName, 'w') as fp:
             s = 0
-            for k, m in self.model.items():
+            for i, k in enumerate(keys):
+                m = self.model[k]
                 m.report(style='xmgrace', fp=fp)
                 dt = self.DeltaT[k]
                 Ct = self.Decay[k]
-                ymodel = m.eval(dt)
+                ymodel = curves[i]
                 print("@s%d legend \"Res %d\"" % (s, m.name), file=fp)
-                for j in range(len(ymodel)):
-                    print("%8g %8g" % (dt[j], ymodel[j]), file=fp)
+                if blocks is not None:
+                    fp.write(blocks[2 * i])
+                else:
+                    for j in range(len(ymodel)):
+                        print("%8g %8g" % (dt[j], ymodel[j]), file=fp)
                 print('&', file=fp)
-                for j in range(len(ymodel)):
-                    print("%8g %8g" % (dt[j], Ct[j]), file=fp)
+                if blocks is not None:
+                    fp.write(blocks[2 * i + 1])
+                else:
+                    for j in range(len(ymodel)):
+                        print("%8g %8g" % (dt[j], Ct[j]), file=fp)
                 print('&', file=fp)
                 s += 2
 
@@ -668,8 +695,8 @@ def read_fittedCt_parameters(fileName):
     tmpTau = OrderedDict()
     inside = False
     with open(fileName) as fp:
-        for line in fp.readlines():
-            if line.startswith("#"):
+        for line in fp:
+            if line[:1] == "#":
                 l = line.split()
                 if l[1].startswith("Residue"):
                     if inside:

@@ -8,6 +8,8 @@ Reference: general_scripts.py:11-16, 47-67, 182-290; calculate-Ct-from-traj.py:6
 """
 import sys
 
+import os
+
 import numpy as np
 
 
@@ -44,9 +46,49 @@ def load_xys(fn):
     return np.array(x), np.array(y)
 
 
+def _native_lib():
+    """the shared library's host-side text routines (csrc/sr_textio.hip), or None: formatting and parsing text is not device
+    work, so without the library the Python implementations below do the same job (slower)"""
+    try:
+        from . import _lib
+        return _lib.load()
+    except Exception:
+        return None
+
+
+def _load_sxydylist_native(fn, key):
+    """load_sxydylist through sr_text_open_sxydy (threaded strtod parse); None when the file is not the regular case"""
+    lib = _native_lib()
+    if lib is None:
+        return None
+    import ctypes
+    h = lib.sr_text_open_sxydy(os.fsencode(fn), key.encode(), 0)
+    if not h:
+        return None
+    try:
+        info = (ctypes.c_int64 * 6)()
+        if lib.sr_text_sxydy_info(h, info) != 0 or not info[0] or info[1] == 0:
+            return None
+        nsets, npts, has_dy, nbytes = info[1], info[2], info[3], info[5]
+        x = np.empty((nsets, npts))
+        y = np.empty((nsets, npts))
+        dy = np.empty((nsets, npts)) if has_dy else None
+        lb = ctypes.create_string_buffer(max(1, nbytes))
+        if lib.sr_text_sxydy_get(h, x.ctypes.data, y.ctypes.data, dy.ctypes.data if has_dy else None, lb) != 0:
+            return None
+        legs = [t.decode() for t in lb.raw[:nbytes].split(b'\0')[:info[4]]]
+        return legs, x, y, (dy if has_dy else [])
+    finally:
+        lib.sr_text_close_sxydy(h)
+
+
 def load_sxydylist(fn, key="legend"):
     """general_scripts.py:182-213: xmgrace multi-set file with `@s<i> legend "<name>"` lines; sets end at '&'.
-    Returns (legends, x[nset, npts], y, dy) -- dy is [] when the file has no third column."""
+    Returns (legends, x[nset, npts], y, dy) -- dy is [] when the file has no third column.  Regular files (every set the same
+    length, two or three plain numeric columns) are parsed natively; everything else line by line as the reference does."""
+    got = _load_sxydylist_native(fn, key)
+    if got is not None:
+        return got
     legs, xs, ys, dys = [], [], [], []
     x, y, dy = [], [], []
     for l in open(fn):
@@ -181,6 +223,20 @@ def print_sxylist(fn, legend, x, ylist, header=[]):
     ylist = np.array(ylist)
     xs = [str(v) for v in x]
     fast = ylist.dtype == np.float64 and ylist.ndim == 3 and ylist.shape[2] == 2
+    if fast and len(xs) == ylist.shape[1]:
+        # the same bytes from the library's threaded formatter (csrc/sr_textio.hip); rows outside the regular formats make it
+        # decline (return code 1) and the code below writes the file
+        lib = _native_lib()
+        if lib is not None:
+            y = np.ascontiguousarray(ylist, dtype=np.float64)
+            legs = b''.join(('@s%d legend "%s"' % (i, legend[i])).encode() + b'\0' for i in range(y.shape[0]))
+            xsb = b''.join(v.encode() + b'\0' for v in xs)
+            hdr = ''.join('%s\n' % line for line in header).encode()
+            rc = lib.sr_text_write_sxydy_f64(os.fsencode(fn), hdr, y.shape[0], y.shape[1], legs, xsb, y.ctypes.data, 0)
+            if rc == 0:
+                return
+            if rc < 0:
+                raise IOError('cannot write %s' % fn)
     with open(fn, 'w') as fp:
         for line in header:
             print("%s" % line, file=fp)

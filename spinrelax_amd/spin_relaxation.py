@@ -15,7 +15,14 @@ parts, and the objective for any csa is a closed form of 12 numbers -- algebraic
 import sys
 
 import numpy as np
-from scipy.optimize import fmin_powell
+
+
+def fmin_powell(*args, **kwargs):
+    """scipy.optimize.fmin_powell, imported when an optimisation is really run: importing scipy.optimize costs 0.2 s, a third of
+    the wall time of a plain calculate-relaxations-from-Ct.py run that never optimises anything"""
+    from scipy.optimize import fmin_powell as f
+    return f(*args, **kwargs)
+
 
 from . import hip
 from . import dist as srdist

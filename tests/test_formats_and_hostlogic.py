@@ -245,3 +245,85 @@ def test_fast_pair_formatter_equals_numpy_str():
         fast = gs._numpy_str_pairs(y)
         for j in range(len(y)):
             assert fast[j] == str(y[j]).strip('[]'), (y[j], fast[j])
+
+
+def _pair_sets(n=20000):
+    rng = np.random.RandomState(5)
+    sets = [np.stack((rng.rand(n), rng.rand(n) * 1e-2), -1), np.stack((rng.rand(n), rng.rand(n) * 1e-4), -1),
+            np.stack((rng.rand(n) * 2 - 1, 10.0 ** rng.uniform(-12, 9, n) * rng.choice([-1, 1], n)), -1)]
+    sp = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 0.25, 1e-4, 9.9999e-5, 1e-5, 1e8, 99999999.0, 123456789.0, 1e3, 999.9, 1000.1, 0.1,
+                   0.123456785, 0.123456775, 1.23449999999e-3, 2.5, 1 / 3., 2 / 3., 1e-98, 1e99, 7.0, 1e22, 123.456, 9.5e-5, 1e-7])
+    sets.append(np.array([(a, b) for a in sp for b in sp]))
+    dec = rng.randint(0, 9, n)
+    sets.append(np.stack([np.round(rng.rand(n), d) for d in range(9)], 0)[dec, np.arange(n)][:, None] * 10.0 ** rng.randint(-6, 6, (n, 2)))
+    return sets
+
+
+def test_native_Ctint_writer_and_reader_equal_the_python_ones(tmp_path, monkeypatch):
+    """csrc/sr_textio.hip (host code of the shared library): sr_text_write_sxydy_f64 writes the bytes print_sxylist writes, and
+    sr_text_open_sxydy reads the doubles and legends load_sxydylist reads -- over positional and scientific rows, the switch
+    points of numpy's printer, headers, quoted legends; rows it does not format (non-finite, three-digit exponents) and files
+    that are not regular (ragged sets, no closing '&', junk) make it decline, and the Python path takes over."""
+    from spinrelax_amd import general_scripts as gs
+    assert gs._native_lib() is not None, 'libspinrelax_hip.so must load (host entry points need no GPU)'
+    sets = _pair_sets()
+    m = min(len(y) for y in sets)
+    ylist = np.stack([y[:m] for y in sets], 0)                       # (5, m, 2)
+    x = np.arange(1, m + 1) * 0.001
+    legend = ['%d' % (i + 1) for i in range(len(ylist))]
+    header = ['# first line', '@ title "x"']
+    fa, fb = str(tmp_path / 'native.dat'), str(tmp_path / 'python.dat')
+    gs.print_sxylist(fa, legend, x, ylist, header)
+    with monkeypatch.context() as mp:
+        mp.setattr(gs, '_native_lib', lambda: None)
+        gs.print_sxylist(fb, legend, x, ylist, header)
+        want = gs.load_sxydylist(fb)
+    assert open(fa, 'rb').read() == open(fb, 'rb').read()
+    got = gs.load_sxydylist(fa)
+    assert gs._load_sxydylist_native(fa, 'legend') is not None
+    assert got[0] == want[0] == legend
+    for a, b in zip(got[1:], want[1:]):
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
+    # rows the native formatter declines: the file is still written, by the Python path, byte for byte what numpy prints
+    odd = ylist.copy()
+    odd[2, 7] = (np.nan, 1.0)
+    odd[3, 9] = (1e-120, 1.0)
+    gs.print_sxylist(fa, legend, x, odd)
+    with monkeypatch.context() as mp:
+        mp.setattr(gs, '_native_lib', lambda: None)
+        gs.print_sxylist(fb, legend, x, odd)
+    assert open(fa, 'rb').read() == open(fb, 'rb').read()
+    # two-column sets (no dy), and irregular files
+    two = str(tmp_path / 'two.dat')
+    gs.print_xylist(two, x[:50], ylist[:3, :50, 0])
+    a = gs._load_sxydylist_native(two, 'legend')
+    with monkeypatch.context() as mp:
+        mp.setattr(gs, '_native_lib', lambda: None)
+        b = gs.load_sxydylist(two)
+    assert a is not None and a[0] == b[0] == [] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == [] and b[3] == []
+    for text in ('@s0 legend "a"\n1 2 3\n2 3 4\n&\n@s1 legend "b"\n1 2 3\n&\n',          # ragged
+                 '@s0 legend "a"\n1 2 3\n2 3 4\n',                                      # no closing '&'
+                 '@s0 legend "a"\n1 2 3\n2 x 4\n&\n',                                   # junk
+                 '@s0 legend "a"\n1 2 3 4\n&\n',                                        # more columns
+                 '@s0 legend "a"\n&\n'):                                                # empty set
+        f = str(tmp_path / 'irr.dat')
+        open(f, 'w').write(text)
+        assert gs._load_sxydylist_native(f, 'legend') is None
+
+
+def test_native_g8_rows_equal_python_formatting(tmp_path):
+    """the "%8g %8g" rows of _fittedCt.dat (fitting_Ct_functions.py:107-126) from sr_text_format_g8_pairs"""
+    import ctypes
+    from spinrelax_amd import general_scripts as gs
+    lib = gs._native_lib()
+    rng = np.random.RandomState(2)
+    a = np.concatenate([10.0 ** rng.uniform(-12, 12, 5000) * rng.choice([-1, 1], 5000), [0.0, -0.0, 1.0, 100000.0, 999999.5, 1e6, 1e-5, 0.0001, 123456.7]])
+    b = np.concatenate([rng.rand(5000), [1.0, 0.5, 1e-300, 1e300, 12345678.0, 0.1, 1 / 3., 2.5e-7, 5e-324]])
+    buf = ctypes.create_string_buffer(32 * a.size)
+    bounds = np.array([0, 17, 17, 4000, a.size], dtype=np.int64)
+    offs = np.empty(bounds.size, dtype=np.int64)
+    n = lib.sr_text_format_g8_pairs(a.ctypes.data, b.ctypes.data, a.size, buf, 32 * a.size, 4, bounds.ctypes.data, bounds.size, offs.ctypes.data)
+    assert n > 0
+    rows = ["%8g %8g\n" % (a[j], b[j]) for j in range(a.size)]
+    assert buf.raw[:n].decode('ascii') == ''.join(rows)
+    assert offs.tolist() == [sum(len(r) for r in rows[:k]) for k in bounds]

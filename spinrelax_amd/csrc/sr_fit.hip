@@ -1510,8 +1510,16 @@ __device__ __noinline__ void search_order(const R T, const SearchArgs &a, int j,
 #ifndef SR_FIT_WAVES_EU
 #define SR_FIT_WAVES_EU 2     // wavefronts per SIMD the register budget allows: 2 -> 256 VGPRs, 3 -> 168
 #endif
+// SR_FIT_WAVES_EU_LOW: register budget of the variant that only knows orders <= 5.  Orders 2, 3 and 5 are a third of the search's
+// cost with the chip full (0.128 + 0.105 + 0.043 of 0.72 ms per batch, scripts/dev/fit_by_order.py) although their fits are
+// tiny, so more resident workgroups were tried for them: 3 / 4 waves per SIMD (168 / 128 VGPRs: 592 / 840 B of scratch) with the
+// residue in LDS or in global memory -- 0.289 / 0.337 ms (LDS), 0.316 / 0.360 (global) against 0.276 at two waves: they are
+// issue-bound like the high orders, not waiting for latency.
+#ifndef SR_FIT_WAVES_EU_LOW
+#define SR_FIT_WAVES_EU_LOW SR_FIT_WAVES_EU
+#endif
 template <int NMAX, int W, bool LDS>
-__global__ __launch_bounds__(W * 64, SR_FIT_WAVES_EU) void k_order_search(SearchArgs a)
+__global__ __launch_bounds__(W * 64, NMAX <= 5 ? SR_FIT_WAVES_EU_LOW : SR_FIT_WAVES_EU) void k_order_search(SearchArgs a)
 {
     const int res = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x;

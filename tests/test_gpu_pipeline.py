@@ -254,6 +254,48 @@ def test_pipeline_with_orientation_trajectory(setup):
         DevicePipeline(st['ctx'], st['dev'], s['frames'], 32, s['R'], s['F'], s['dt'], q_orient=g['q32'][:5], **kw)
 
 
+@pytest.mark.parametrize('variant', ['isotropic', 'csa_per_residue', 'orientation_trajectory'])
+def test_grouped_schedule_variants_equal_the_serial_pipeline(setup, variant):
+    """the other shapes of the path through the grouped schedule: no histogram weights (isotropic diffusion), a CSA value per
+    residue (the relaxation constants are tiled over the group's batches), de-tumbling inside the pack"""
+    from conftest import golden
+    from spinrelax_amd.pipeline import DevicePipeline, GroupedPipeline
+    st = setup
+    s, synth, torch = st['s'], st['synth'], st['torch']
+    V = st['vecs'].shape[1]
+    vecs = st['dvecs']
+    kw = dict(Diso=synth.DISO, field_MHz=(synth.FIELD_MHZ, 700.0), zeta=synth.ZETA)
+    if variant == 'isotropic':
+        kw.update(q_rot=None, aniso=None)
+    elif variant == 'csa_per_residue':
+        kw.update(q_rot=synth.Q_EXT, aniso=synth.DANI, csa=-170e-6 + 1e-6 * np.arange(V))
+    else:
+        g = golden('cfg1_detumble.npz')
+        V = 32
+        vecs = torch.from_numpy(g['lab']).to(st['dev'])
+        kw.update(q_rot=synth.Q_EXT, aniso=synth.DANI, q_orient=g['q32'])
+    serial = DevicePipeline(st['ctx'], st['dev'], s['frames'], V, s['R'], s['F'], s['dt'], depth=1,
+                            stream=torch.cuda.Stream(device=st['dev']), **kw)
+    serial.step(vecs)
+    torch.cuda.synchronize()
+    want = {k: v.copy() for k, v in serial.slots[0].result.items()}
+    want_hist = serial.slots[0].hist.cpu().numpy()
+    serial.close()
+    for late in (True, False):
+        pipe = GroupedPipeline(st['ctx'], st['dev'], s['frames'], V, s['R'], s['F'], s['dt'], group=3, late_hist=late,
+                               stream=torch.cuda.Stream(device=st['dev']), **kw)
+        seen = []
+        pipe.run(vecs, 5, None, lambda b: seen.append(({k: v.copy() for k, v in b.result.items()}, b.hist.cpu().numpy())))
+        torch.cuda.synchronize()
+        assert len(seen) == 5
+        for r, hist in seen:
+            for k in want:
+                assert np.array_equal(r[k], want[k], equal_nan=True), (variant, late, k)
+            if variant != 'isotropic':
+                assert np.array_equal(hist, want_hist)
+        pipe.close()
+
+
 def test_full_size_batch_search_equals_host_driven_search():
     """BASELINE cfg3, one full batch (100 000 frames x 512 vectors, L = 2048): the one-launch model-order search inside
     the pipeline against the host-driven search that calls the single-order solver order by order -- identical

@@ -89,6 +89,11 @@ __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 #ifndef SR_FIT_LP
 #define SR_FIT_LP 0
 #endif
+// Tried and dropped (round 3): parking the solver's workgroup-uniform n-vectors (x, g, d, g_h, the trial point) in a per-wave LDS
+// area across the model / Jacobian passes -- explicit stores before, volatile loads behind -- so that the register allocator
+// has nothing of them to spill: it spilled MORE (1 256 B per lane instead of 776, 216 scratch loads per solver iteration instead
+// of 75): the copies and the volatile loads lengthen other live ranges in the n x n algebra.  The frame that remains is the
+// allocator's choice of victims in ~7 000 instructions of straight-line algebra, not a set of values one can name.
 #ifndef SR_FIT_SETPRIO
 #define SR_FIT_SETPRIO 3     // wave priority of the model-order search (0 = default priority)
 #endif

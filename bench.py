@@ -680,9 +680,11 @@ def main():
                                    '%s, fits 2/3/5/7/9 params, 1 field' % (cfg, s['frames'], V, s['R'], s['F'], s['L'],
                                                                            'axisymmetric D + q_ext + 72x36 histogram' if cfg == 3 else 'isotropic D'),
                        'vectors_per_gpu': V, 'exact_triples_per_gpu': triples, 'sharding': 'vectors (no data-path collective; all-gather of results)',
-                       'schedule': ('grouped: C(t) / histogram / chunk statistics of %d batches back to back, then ONE merged model-order search + '
-                                    'relaxation launch over their %d residues (dispatched in a fixed pseudo-random order); next group%s'
-                                    % (group_used, group_used * V, ' overlaps it' if not args.no_group_overlap else ' waits for it'))
+                       'schedule': ('grouped: pack / C(t) / chunk statistics%s of %d batches back to back, then ONE merged model-order search + '
+                                    'relaxation launch over their %d residues (dispatched in a fixed pseudo-random order)%s; next group%s'
+                                    % ('' if args.late_hist else ' / histogram', group_used, group_used * V,
+                                       ', their histograms in the tail of that launch (released by a signal its last workgroup writes)' if args.late_hist else '',
+                                       ' overlaps it' if not args.no_group_overlap else ' waits for it'))
                                    if grouped else 'per batch: every batch launches its own fits, %d batches in flight' % depth_used,
                        'batches_per_group': group_used, 'batches_in_flight': group_used if grouped else depth_used, 'cus_reserved_for_fits': reserve_used},
             'roofline': roofline,

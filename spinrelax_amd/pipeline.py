@@ -732,8 +732,16 @@ class GroupedPipeline(DevicePipeline):
         self.hist_stream = torch.cuda.Stream(device=device) if self.late_hist else None
         self._late = []
         self._hist_done_ev = [None] * self.NB           # late histograms: "the histogram that read this plane buffer has run"
-        for grp in self.groups:
-            grp.signal, grp.epoch = ctx.signal_alloc(), 0
+        from .hip import SpinRelaxHipError
+        try:
+            for grp in self.groups:
+                grp.signal, grp.epoch = None, 0
+                grp.signal = ctx.signal_alloc()
+        except SpinRelaxHipError:
+            # a device / runtime without stream waits on memory values: the histograms run beside the C(t) kernels instead
+            if self.late_hist:
+                raise SpinRelaxHipError('late_hist needs sr_signal_alloc (hipStreamWaitValue32 on signal memory); construct the '
+                                        'pipeline with late_hist=False on this device')
         # gate_next: hold the next group's C(t) launches back (same signal) until the merged launch begins to drain.  Measured, off:
         # 2.13 against 2.115 ms per step in steady state (queued behind a launch that fills the chip they hardly get a slot before
         # that moment anyway), and no help to unequal splits of a 20-batch run (16 + 4, 14 + 6, ...: 49-51 ms like one group of
@@ -889,12 +897,13 @@ class GroupedPipeline(DevicePipeline):
                                                   v['tau'].data_ptr(), v['chi'].data_ptr(), v['K'].data_ptr(),
                                                   work_ptr=grp.fitwork.data_ptr(),
                                                   dispatch_order_ptr=self._dispatch_order(g).data_ptr() if self.permute else None,
-                                                  tail_signal=grp.signal, tail_value=grp.epoch + 1)
+                                                  tail_signal=grp.signal, tail_value=grp.epoch + 1 if grp.signal else 0)
             if events is not None and len(events) > 5:
                 events[5].record(st)
-            grp.epoch += 1
-            self.ctx.stream_write_signal(grp.signal, grp.epoch)
-            self._prev_signal = (grp.signal, grp.epoch)
+            if grp.signal:
+                grp.epoch += 1
+                self.ctx.stream_write_signal(grp.signal, grp.epoch)
+                self._prev_signal = (grp.signal, grp.epoch)
             if self.late_hist:
                 # The group's histograms fill the TAIL of the merged launch.  Its last workgroup releases the signal when it
                 # starts (every residue has a CU by then; from here on slots only free up while the longest fits finish); the

@@ -370,6 +370,7 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['steps'] == 4
     assert j['config']['vectors_per_gpu'] == 64 and j['value'] > 0
     assert j['fit']['residues'] == 64 and j['fit']['unfitted'] == 0
+    assert j['config']['schedule'].startswith('grouped') and j['config']['batches_per_group'] == 4   # the default schedule, with its gathers
 
 
 def test_bench_single_rank_under_torchrun_equals_plain_run():

@@ -599,6 +599,7 @@ class _Group:
         self.busy = False
         self.batches = []
         self._views = {}
+        self._dpool, self._ipool = [], []
 
     def _layouts(self, g):
         nO, Pmax, Kmax, E = self._shape
@@ -652,12 +653,31 @@ class _Group:
         b.index = j
         return b
 
+    def _host_copy(self, pool, mirror, n):
+        """the first n elements of a pinned mirror in pageable memory the caller may keep.  The buffers are recycled: one is taken
+        again only when nothing outside the pool refers to it any more (every array handed out is a view that keeps its base
+        alive), so results stay valid for as long as anybody holds them -- and a collect does not start with a 10 MB allocation
+        and its page faults (1.5 ms when the allocator has just seen another size)."""
+        import sys
+        buf = None
+        for b in pool:
+            if sys.getrefcount(b) <= 3:          # the pool's reference, `b`, getrefcount's argument
+                buf = b
+                break
+        if buf is None:
+            buf = np.empty(mirror.size, dtype=mirror.dtype)
+            if len(pool) < 4:
+                pool.append(buf)
+        np.copyto(buf[:n], mirror[:n])
+        return buf[:n]
+
     def host_results(self):
         """per batch: COPIES of the pinned mirrors, split along the residue axis"""
         g, V = self.g, self.V
         nd, ni = self._sizes(g)
         whole = {}
-        for buf, layout in zip((self.h_dres[:nd].copy(), self.h_ires[:ni].copy()), self._layouts(g)):
+        for buf, layout in zip((self._host_copy(self._dpool, self.h_dres, nd), self._host_copy(self._ipool, self.h_ires, ni)),
+                               self._layouts(g)):
             o = 0
             for name, sh, axis in layout:
                 n = int(np.prod(sh))

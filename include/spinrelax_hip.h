@@ -184,6 +184,9 @@ int sr_rotate_vectors_perframe_f32(sr_ctx *, const float *vecs, int64_t N, int64
  *   sr_vectors_ct_f32        kernel 0 (once per object) + kernel 1: as sr_ct_palmer_f32, Ct / dCt (F/2, nV) on the host
  *   sr_vectors_hist_f32      kernel 0 (once per object) + kernel 2 over the first N_hist frames (<= 0: all): as
  *                            sr_rotate_hist_f32
+ * Stream ordering: an append leaves its copies in flight on the context's current stream and records an event behind
+ * them; every consumer (ct, ct_sums, hist, download) first makes ITS current stream wait for that event, so sr_set_stream
+ * between an append and the next use loses no ordering.  chunk_start_host tables are range-checked against the frames held.
  * sr_counter(ctx, "h2d_vector_bytes" | "vector_uploads"): bytes and calls of sr_vectors_append_f32 since sr_create (the
  * host-pointer entry points sr_ct_palmer_f32 / sr_rotate_hist_f32 go through it too). */
 typedef struct sr_vectors sr_vectors;

@@ -142,21 +142,31 @@ def load_mdtraj(args, frames_per_chunk_of):
         nchunk = args.nSplitFrames if args.nSplitFrames > 0 else 1000
         file_start = 0 if lab is None else lab.frames
         nfile = 0
+        iX = iH = None
         for trj in md.iterload(fn, chunk=nchunk, top=top):
-            names = [trj.topology.atom(k).residue.resSeq for k in trj.topology.select(args.Hseltxt)]
-            d = trj.timestep
-            iX, iH = select(trj)
-            if resXH is None:
-                resXH, dt, V = names, d, len(iX)
-                i0, nloc = srdist.my_range(V) if srdist.world() > 1 else (0, V)
-                if nloc > 0:
-                    lab, fit = ctx.vectors(nloc), ctx.vectors(nloc)
-            elif dt != d or resXH != names:
-                print("= = = ERROR: Differences in trajectories have been detected! Aborting.", file=sys.stderr)
-                sys.exit(1)
+            if iX is None:
+                # names, selections and the time step come from a file's FIRST chunk only, as in the reference (:436-438):
+                # a later chunk may hold a single frame (MDTraj's .timestep raises for it) and float32 frame times of
+                # later chunks give a time step that differs from the first one in its last bits
+                names = [trj.topology.atom(k).residue.resSeq for k in trj.topology.select(args.Hseltxt)]
+                d = float(trj.timestep)
+                iX, iH = select(trj)
+                if resXH is None:
+                    resXH, dt, V = names, d, len(iX)
+                    i0, nloc = srdist.my_range(V) if srdist.world() > 1 else (0, V)
+                    if nloc > 0:
+                        lab, fit = ctx.vectors(nloc), ctx.vectors(nloc)
+                elif dt != d or resXH != names:
+                    print("= = = ERROR: Differences in trajectories have been detected! Aborting.", file=sys.stderr)
+                    print("      ...delta-t: %g vs.%g " % (dt, d), file=sys.stderr)
+                    print("      ...n-bonds: %g vs.%g " % (V, len(iX)), file=sys.stderr)
+                    sys.exit(1)
             if nloc > 0:
                 hip.append_xyz(ctx, lab, fit, trj.xyz, iX[i0:i0 + nloc], iH[i0:i0 + nloc], fi, ref.xyz[0])
             nfile += trj.xyz.shape[0]
+        if iX is None:
+            print("= = = ERROR: trajectory file %s holds no frames!" % fn, file=sys.stderr)
+            sys.exit(1)
         F = frames_per_chunk_of(dt)
         keep = nfile if F is None else (nfile // F) * F
         if nloc > 0 and keep != nfile:

@@ -20,6 +20,8 @@ struct sr_vectors {
     float *soa;            // (nV, 3, Npad) planes, device; built by the first computation
     int64_t Npad;
     int packed;            // planes are current
+    hipEvent_t ready;      // recorded behind the last append / pack on the stream that did it: a consumer on ANOTHER stream
+                           // (sr_set_stream between an append and the next use) waits for it on the device
 };
 
 namespace {
@@ -60,8 +62,23 @@ int reserve(sr_ctx *ctx, sr_vectors *h, int64_t frames)
     return 0;
 }
 
+int mark_ready(sr_ctx *ctx, sr_vectors *h)
+{
+    if (!h->ready) SR_HIP(hipEventCreateWithFlags(&h->ready, hipEventDisableTiming));
+    SR_HIP(hipEventRecord(h->ready, ctx->stream));
+    return 0;
+}
+
+/* the contents of h (frames and planes) are valid on ctx->stream behind this call, whichever stream wrote them */
+int wait_ready(sr_ctx *ctx, sr_vectors *h)
+{
+    if (h->ready) SR_HIP(hipStreamWaitEvent(ctx->stream, h->ready, 0));
+    return 0;
+}
+
 int pack(sr_ctx *ctx, sr_vectors *h)
 {
+    if (int rc = wait_ready(ctx, h)) return rc;
     if (h->packed) return 0;
     SR_REQUIRE(h->N > 0, -3, "sr_vectors: no frames appended");
     const int64_t Npad = sr_round_up(h->N, 64);
@@ -77,7 +94,7 @@ int pack(sr_ctx *ctx, sr_vectors *h)
     int rc = sr_pack_soa_f32_dev(ctx, h->fm, h->N, h->nV, 0, h->nV, h->soa, Npad);
     if (rc) return rc;
     h->packed = 1;
-    return 0;
+    return mark_ready(ctx, h);
 }
 
 }  // namespace
@@ -115,6 +132,7 @@ void sr_vectors_destroy(sr_ctx *ctx, sr_vectors *h)
     }
     if (h->fm) (void)hipFree(h->fm);
     if (h->soa) (void)hipFree(h->soa);
+    if (h->ready) (void)hipEventDestroy(h->ready);
     free(h);
 }
 
@@ -164,7 +182,7 @@ int sr_vectors_append_f32(sr_ctx *ctx, sr_vectors *h, const float *vecs, int64_t
     ctx->h2d_calls += 1;
     h->N += n;
     h->packed = 0;
-    return 0;
+    return mark_ready(ctx, h);               // the copies are still in flight on ctx->stream: a later use on another stream waits
 }
 
 int sr_vectors_append_dev(sr_ctx *ctx, sr_vectors *h, const float *vecs_dev, int64_t n)
@@ -178,7 +196,7 @@ int sr_vectors_append_dev(sr_ctx *ctx, sr_vectors *h, const float *vecs_dev, int
                           ctx->stream));
     h->N += n;
     h->packed = 0;
-    return 0;
+    return mark_ready(ctx, h);
 }
 
 int sr_vectors_append_xyz_f32(sr_ctx *ctx, sr_vectors *lab, sr_vectors *fit, const float *xyz, int64_t nFrames, int64_t nAtoms,
@@ -211,6 +229,7 @@ int sr_vectors_download_f32(sr_ctx *ctx, const sr_vectors *h, int64_t f0, int64_
     SR_REQUIRE(h && out, -2, "sr_vectors_download_f32: null pointer");
     SR_REQUIRE(f0 >= 0 && n >= 1 && f0 + n <= h->N, -3, "sr_vectors_download_f32: frames [%lld, %lld) out of range", (long long)f0, (long long)(f0 + n));
     const size_t row = (size_t)h->nV * 3 * sizeof(float);
+    if (int rc = wait_ready(ctx, const_cast<sr_vectors *>(h))) return rc;
     SR_HIP(hipMemcpyAsync(out, reinterpret_cast<const char *>(h->fm) + (size_t)f0 * row, (size_t)n * row, hipMemcpyDeviceToHost, ctx->stream));
     SR_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -250,6 +269,9 @@ int sr_vectors_ct_sums_f32(sr_ctx *ctx, sr_vectors *h, int64_t R, int64_t F, con
     double *psum = (double *)sr_workspace(ctx, SR_WS_PSUM, (size_t)(h->nV * R * Lp) * sizeof(double));
     if (!psum) return -5;
     if (!chunk_start_host) SR_REQUIRE(R * F <= h->N, -3, "sr_vectors_ct_sums_f32: R*F=%lld exceeds the %lld frames held", (long long)(R * F), (long long)h->N);
+    else
+        for (int64_t r = 0; r < R; ++r)
+            SR_REQUIRE(chunk_start_host[r] >= 0 && chunk_start_host[r] + F <= h->N, -3, "sr_vectors_ct_sums_f32: chunk %lld out of range", (long long)r);
     int rc = sr_ct_palmer_sums_f32_dev(ctx, h->soa, h->Npad, R, F, h->nV, chunk_start_host, mode, psum);
     if (rc) return rc;
     SR_HIP(hipMemcpy2DAsync(sums, (size_t)L * sizeof(double), psum + 1, (size_t)Lp * sizeof(double), (size_t)L * sizeof(double),

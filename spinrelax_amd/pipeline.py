@@ -34,6 +34,7 @@ the first HIP call (bench.py does).  CU-masked streams (`reserve_cus`, `aux_cus`
 for the bandwidth kernels) are kept as options of DevicePipeline; neither pays on MI355X.
 """
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -561,6 +562,17 @@ class DevicePipeline:
 # ======================================================================================================================
 # Grouped schedule: throughput halves of G batches back to back, then ONE merged launch for their latency halves
 # ======================================================================================================================
+class _Lease:
+    """one hand-out of a recycled host buffer: exposes the memory through the array interface, so that numpy arrays made
+    from it (np.asarray) and all their views hold a reference to THIS object; when the last of them is gone the lease is
+    collected and _Group._host_copy may reuse the buffer"""
+    __slots__ = ('__array_interface__', '_keep', '__weakref__')
+
+    def __init__(self, arr):
+        self._keep = arr
+        self.__array_interface__ = dict(arr.__array_interface__)
+
+
 class _BatchView:
     """What the stage functions need of one batch inside a group (views into the group's contiguous buffers)."""
     __slots__ = ('Ct', 'dCt', 'CtT', 'dCtT', 'hist', 'vecsum', 'outer', 'psum', 'result', 'relax_out', 'index')
@@ -654,22 +666,26 @@ class _Group:
         return b
 
     def _host_copy(self, pool, mirror, n):
-        """the first n elements of a pinned mirror in pageable memory the caller may keep.  The buffers are recycled: one is taken
-        again only when nothing outside the pool refers to it any more (every array handed out is a view that keeps its base
-        alive), so results stay valid for as long as anybody holds them -- and a collect does not start with a 10 MB allocation
-        and its page faults (1.5 ms when the allocator has just seen another size)."""
-        import sys
-        buf = None
-        for b in pool:
-            if sys.getrefcount(b) <= 3:          # the pool's reference, `b`, getrefcount's argument
-                buf = b
+        """the first n elements of a pinned mirror in pageable memory the caller may keep.  The buffers are recycled, with
+        explicit ownership: every hand-out goes through a fresh _Lease object that the returned array (and every view cut
+        from it) keeps alive as its base; a pool buffer is taken again only when the lease of its last hand-out is gone
+        (a dead weak reference) -- no interpreter-specific reference counts.  Results stay valid for as long as anybody holds
+        them, and a collect does not start with a 10 MB allocation and its page faults (1.5 ms when the allocator has just
+        seen another size).  Where leases die late (no reference counting) the pool simply is not reused."""
+        entry = None
+        for e in pool:
+            if e[1] is None or e[1]() is None:
+                entry = e
                 break
-        if buf is None:
-            buf = np.empty(mirror.size, dtype=mirror.dtype)
+        if entry is None:
+            entry = [np.empty(mirror.size, dtype=mirror.dtype), None]
             if len(pool) < 4:
-                pool.append(buf)
+                pool.append(entry)
+        buf = entry[0]
         np.copyto(buf[:n], mirror[:n])
-        return buf[:n]
+        lease = _Lease(buf[:n])
+        entry[1] = weakref.ref(lease)
+        return np.asarray(lease)
 
     def host_results(self):
         """per batch: COPIES of the pinned mirrors, split along the residue axis"""
@@ -723,14 +739,31 @@ class GroupedPipeline(DevicePipeline):
     bit (a residue's fit does not depend on what else is in the launch).
 
     The next group's phase 1 is queued behind the merged launch without waiting for it (`overlap`), so the tail of one
-    group's stragglers is covered by the next group's C(t) kernels; two group buffers alternate."""
+    group's stragglers is covered by the next group's C(t) kernels; two group buffers alternate.  With `late_hist` that
+    overlap is bounded by the plane buffers: the next group's packs wait for the previous group's histograms (which run in
+    the merged launch's tail) once the 3 spare plane buffers are taken, i.e. about three batches of the next group start
+    before the previous merged launch reaches its tail -- the overlap covers the tail, not the bulk.  Memory: group + 3
+    plane buffers (12 B per frame and vector each; 21 GB for 32 cfg3 batches) + two group buffers (1.7 GB each); checked
+    against the free device memory at construction (falls back to late_hist off, see `late_hist_note`)."""
 
     def __init__(self, ctx, device, frames, V, R, F, dt, group=32, overlap=True, psum_buffers=3, late_hist=True, **kw):
         kw = dict(kw)
         kw['depth'] = max(2, int(psum_buffers))          # the base class's slots: only their raw-sum buffers are used (a rotating pool)
         self.late_hist = bool(late_hist)
+        self.late_hist_note = None
         if self.late_hist:
-            kw['plane_buffers'] = max(1, int(group)) + 3       # a group's planes stay alive until its histograms ran (in phase 2)
+            # a group's planes stay alive until its histograms ran (in phase 2): group + 3 plane buffers of 12 B per (frame,
+            # vector) each -- 35 x 0.6 GB = 21 GB for groups of 32 cfg3 batches.  When that is more than half of the free
+            # device memory the histograms go back beside the C(t) kernels (late_hist off) instead of failing later in an
+            # allocation; `late_hist_note` says so.
+            need = (max(1, int(group)) + 3) * 12 * int(frames) * int(V)
+            free = torch.cuda.mem_get_info(device)[0]
+            if need > free // 2:
+                self.late_hist = False
+                self.late_hist_note = ('late_hist off: %d plane buffers need %.1f GB, %.1f GB of device memory are free'
+                                       % (max(1, int(group)) + 3, need / 1e9, free / 1e9))
+        if self.late_hist:
+            kw['plane_buffers'] = max(1, int(group)) + 3
         for name in ('reserve_cus', 'aux_cus'):
             if kw.get(name):
                 raise ValueError('GroupedPipeline runs its phases on the whole chip: %s is not supported' % name)
@@ -753,13 +786,18 @@ class GroupedPipeline(DevicePipeline):
         self._late = []
         self._hist_done_ev = [None] * self.NB           # late histograms: "the histogram that read this plane buffer has run"
         from .hip import SpinRelaxHipError
+        for grp in self.groups:                           # every group has both attributes whatever the allocation does
+            grp.signal, grp.epoch = None, 0
         try:
             for grp in self.groups:
-                grp.signal, grp.epoch = None, 0
                 grp.signal = ctx.signal_alloc()
         except SpinRelaxHipError:
             # a device / runtime without stream waits on memory values: the histograms run beside the C(t) kernels instead
+            for grp in self.groups:
+                grp.signal = None
             if self.late_hist:
+                self.slots = self.pool
+                super().close()
                 raise SpinRelaxHipError('late_hist needs sr_signal_alloc (hipStreamWaitValue32 on signal memory); construct the '
                                         'pipeline with late_hist=False on this device')
         # gate_next: hold the next group's C(t) launches back (same signal) until the merged launch begins to drain.  Measured, off:

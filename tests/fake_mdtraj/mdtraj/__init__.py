@@ -35,10 +35,27 @@ class Topology:
 
 
 class Trajectory:
-    def __init__(self, xyz, top, timestep):
+    """xyz + float32 frame times, as MDTraj holds them for an .xtc file.  `timestep` is MDTraj's property: time[1] - time[0]
+    of THIS object's frames, and it raises for a single frame -- so a caller that asks every chunk of an iterload for it
+    fails on a one-frame last chunk, and sees last-bit differences between chunks for a time step like 0.1 ps."""
+    def __init__(self, xyz, top, time):
         self.xyz = xyz
         self.topology = top
-        self.timestep = timestep
+        self.time = np.asarray(time, dtype=np.float32)
+
+    @property
+    def n_frames(self):
+        return self.xyz.shape[0]
+
+    @property
+    def timestep(self):
+        if self.n_frames <= 1:
+            raise ValueError("Cannot calculate timestep if trajectory has one frame.")
+        return self.time[1] - self.time[0]
+
+
+def _times(f0, f1, dt):
+    return (np.arange(f0, f1, dtype=np.float64) * float(dt)).astype(np.float32)
 
 
 def _open(fn):
@@ -49,11 +66,12 @@ def _open(fn):
 
 def load(fn, top=None):
     z, t = _open(fn)
-    return Trajectory(np.asarray(z['xyz'], dtype=np.float32), t, float(z['dt']))
+    xyz = np.asarray(z['xyz'], dtype=np.float32)
+    return Trajectory(xyz, t, _times(0, xyz.shape[0], z['dt']))
 
 
 def iterload(fn, chunk=100, top=None):
     z, t = _open(fn)
     xyz = np.asarray(z['xyz'], dtype=np.float32)
     for f0 in range(0, xyz.shape[0], chunk):
-        yield Trajectory(xyz[f0:f0 + chunk], t, float(z['dt']))
+        yield Trajectory(xyz[f0:f0 + chunk], t, _times(f0, min(f0 + chunk, xyz.shape[0]), z['dt']))

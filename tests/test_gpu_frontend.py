@@ -94,16 +94,23 @@ def test_script_from_raw_coordinates_to_Ct(ctx, tmp_path):
     assert np.max(np.abs(np.array(Cx).T / Cl - 1)) < 1e-6
 
 
-def test_mdtraj_loader_streams_chunks_into_resident_vectors(tmp_path):
+@pytest.mark.parametrize('dt_ps', [10.0, float(np.float32(0.1))])
+def test_mdtraj_loader_streams_chunks_into_resident_vectors(tmp_path, dt_ps):
     """load_mdtraj of the drop-in script EXECUTED (with tests/fake_mdtraj standing in for the absent MDTraj: it reads files
     and resolves selections, nothing else): two trajectory files read in --split chunks of 128 frames, every chunk's
     coordinates turned into bond vectors + superposition on the GPU and appended to the rank's resident vectors, each
     file's tail cut to whole blocks of memory time.  The files must equal, byte for byte, what the same script writes from
-    the same coordinates given as .npz arrays (the whole-array path)."""
-    s = synth.config_shapes(1)
+    the same coordinates given as .npz arrays (the whole-array path).
+    The first file holds 4 * 128 + 1 frames -- its last chunk is ONE frame, for which MDTraj's .timestep raises -- and the
+    second case has a 0.1 ps time step, whose float32 frame times give every chunk a time step that differs in its last
+    bits: the time step is a property of a file's first chunk only (reference :436-438), compared between files."""
+    s = dict(synth.config_shapes(1))
+    s['dt'], s['tau_memory'] = dt_ps, 100.5 * dt_ps
     F = int(s['tau_memory'] / s['dt'])
-    d1 = synth.synth_coordinates(5 * F + 37, 12, 31)                 # 37 and 63 frames of tail to drop
-    d2 = synth.synth_coordinates(3 * F + 63, 12, 32)
+    assert F == 100
+    n1, n2 = 4 * 128 + 1, 3 * F + 63                                   # 13 and 63 frames of tail to drop
+    d1 = synth.synth_coordinates(n1, 12, 31)
+    d2 = synth.synth_coordinates(n2, 12, 32)
     natoms = d1['xyz'].shape[1]
     resseq = np.zeros(natoms, dtype=int)
     resseq[d1['indexH']] = np.arange(2, 14)
@@ -134,7 +141,7 @@ def test_mdtraj_loader_streams_chunks_into_resident_vectors(tmp_path):
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
         assert p.returncode == 0, p.stdout.decode()[-3000:]
         if mode == 'mdtraj':
-            assert b'%d frames read, %d kept' % (5 * F + 37, 5 * F) in p.stdout and b'%d frames read, %d kept' % (3 * F + 63, 3 * F) in p.stdout
+            assert b'%d frames read, %d kept' % (n1, 5 * F) in p.stdout and b'%d frames read, %d kept' % (n2, 3 * F) in p.stdout
         outs[mode] = out
     for suffix in ('_Ctext.dat', '_Ctint.dat', '_avgvec.dat', '_S2.dat'):
         a, b = open(outs['mdtraj'] + suffix, 'rb').read(), open(outs['arrays'] + suffix, 'rb').read()

@@ -147,6 +147,41 @@ def test_grouped_schedule_gives_the_serial_results_for_every_batch(setup, group,
     pipe.close()
 
 
+def test_grouped_schedule_without_signal_memory(setup, monkeypatch):
+    """A device / runtime without stream waits on signal memory (sr_signal_alloc fails): late_hist=True says what to do, and
+    late_hist=False -- what that message recommends -- runs several groups through BOTH group buffers with the serial results
+    (every group object has its signal / epoch attributes although the first allocation already failed)."""
+    from spinrelax_amd.pipeline import GroupedPipeline
+    from spinrelax_amd.hip import SpinRelaxHipError, Context
+    st = setup
+    s, synth = st['s'], st['synth']
+    serial = _pipe(st, 1)
+    serial.step(st['dvecs'])
+    st['torch'].cuda.synchronize()
+    want = {k: v.copy() for k, v in serial.slots[0].result.items()}
+    serial.close()
+
+    def no_signals(self):
+        raise SpinRelaxHipError('sr_signal_alloc: hipExtMallocWithFlags(hipMallocSignalMemory) not supported (test)')
+    monkeypatch.setattr(Context, 'signal_alloc', no_signals)
+    V = st['vecs'].shape[1]
+    kw = dict(group=2, q_rot=synth.Q_EXT, Diso=synth.DISO, aniso=synth.DANI, field_MHz=(synth.FIELD_MHZ, 500.0), zeta=synth.ZETA)
+    with pytest.raises(SpinRelaxHipError, match='late_hist=False'):
+        GroupedPipeline(st['ctx'], st['dev'], s['frames'], V, s['R'], s['F'], s['dt'], late_hist=True,
+                        stream=st['torch'].cuda.Stream(device=st['dev']), **kw)
+    pipe = GroupedPipeline(st['ctx'], st['dev'], s['frames'], V, s['R'], s['F'], s['dt'], late_hist=False,
+                           stream=st['torch'].cuda.Stream(device=st['dev']), **kw)
+    assert all(g.signal is None and g.epoch == 0 for g in pipe.groups)
+    seen = []
+    pipe.run(st['dvecs'], 5, None, lambda b: seen.append({k: v.copy() for k, v in b.result.items()}), None)
+    st['torch'].cuda.synchronize()
+    assert len(seen) == 5
+    for r in seen:
+        for k in want:
+            assert np.array_equal(r[k], want[k], equal_nan=True), k
+    pipe.close()
+
+
 def test_batched_order_search_entry_point(setup):
     """sr_expfit_order_search_batched_f64_dev: a shared time axis (t_rows = 1) and a dispatch permutation change nothing in the
     results; bad arguments are refused before any launch."""

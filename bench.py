@@ -10,9 +10,13 @@ A "step" is one pass of the whole hot path over one synthetic trajectory shard t
 resident in HBM: pack -> C(t) -> rotation + spherical histogram -> multi-exponential fits with the
 model-order search -> J(omega)/R1/R2/NOE/rho, and for N > 1 the RCCL all-gather of the per-shard results
 (SURVEY.md section 8(e)).  Workload: BASELINE.json configs[2] (100 000 frames x 512 vectors, 2 048 lags,
-axisymmetric D, q_ext rotation + vecHistogram) PER GPU -- the configuration the north-star quotes its
-scaling on; weak scaling: every rank owns its own 512 vectors (rank r = vectors 512 r .. 512 r + 511
-of one synthetic trajectory).  `value` = exact triples of all ranks / wall time of a step (throughput); `latency_ms` = one
+axisymmetric D, q_ext rotation + vecHistogram) -- the configuration the north-star quotes its scaling on --
+or, with `--workload cfg4`, configs[3] (100 000 x 2 048).  `--scaling strong` (default): the workload's vectors are
+FIXED and sharded over the ranks as the product shards them (spinrelax_amd/dist.py:shard_range, contiguous vector ranges:
+calculate-Ct-from-traj.py:225-228 is independent per vector), so N = 1 is the BENCH measurement and N = 8 of cfg3 leaves
+64 vectors per GPU (cfg4: 256 per GPU = BASELINE configs[3]); `--scaling weak`: every rank owns its own 512 vectors
+(rank r = vectors 512 r .. 512 r + 511 of one synthetic trajectory; linear by construction, there is no data-path
+collective).  `value` = exact triples of all ranks / wall time of a step of the slowest rank (throughput); `latency_ms` = one
 batch alone, start to results on the host.  Schedule (spinrelax_amd/pipeline.py:GroupedPipeline, `--group`, default 32): the
 C(t) / histogram / chunk-statistics kernels of a group of steps back to back, then ONE merged model-order search and ONE
 relaxation launch over the group's residues; a run of K steps is cut into groups of min(K, 32), every step's work is done
@@ -73,7 +77,25 @@ def committed_profile():
         return {}, None
     with open(files[-1]) as fp:
         d = json.load(fp)
+    global PROFILE_BUILD_ID
+    PROFILE_BUILD_ID = d.get('build_id')
     return d.get('kernels', {}), os.path.relpath(files[-1], ROOT)
+
+
+PROFILE_BUILD_ID = None
+
+
+def profile_staleness():
+    """Do the committed PMC figures belong to the kernels that ran?  The profile stores the build id (sha256 over the HIP
+    sources, headers and compiler flags, spinrelax_amd/build.py:build_id) of the library it was collected with; the loaded
+    library reports its own (sr_build_id)."""
+    from spinrelax_amd import _lib
+    try:
+        mine = _lib.load().sr_build_id().decode()
+    except Exception:
+        mine = 'unknown'
+    stale = PROFILE_BUILD_ID is None or PROFILE_BUILD_ID != mine
+    return stale, mine
 
 
 def prof_entry(prof, prefix):
@@ -91,8 +113,10 @@ def parse():
     ap.add_argument('--repeats', type=int, default=3, help='the timed region (exactly --steps steps between two synchronisations) is run this many times; value / ms_per_step are the MEDIAN, every sample is listed')
     ap.add_argument('--spinup-s', type=float, default=1.0, help='untimed seconds of the same pipeline before the warm-up steps: a fresh box needs about a second under load before the clocks settle (5 warm-up steps are 15 ms)')
     ap.add_argument('--steady-steps', type=int, default=120, help='steps of the extra (untimed for the headline) long run behind ms_per_step_steady; 0 = skip')
-    ap.add_argument('--workload', type=str, default='cfg3', choices=['cfg2', 'cfg3'])
-    ap.add_argument('--vectors', type=int, default=None, help='vectors per GPU (default: the config value)')
+    ap.add_argument('--workload', type=str, default='cfg3', choices=['cfg2', 'cfg3', 'cfg4'])
+    ap.add_argument('--scaling', type=str, default='strong', choices=['strong', 'weak'],
+                    help='strong (default): the workload\'s vectors are fixed and sharded over the ranks (N = 1 is the BENCH run); weak: every rank owns the full vector count')
+    ap.add_argument('--vectors', type=int, default=None, help='vectors of the workload (strong scaling: in total, sharded over the ranks; weak: per GPU); default: the config value')
     ap.add_argument('--reserve-cus', type=int, default=0, help='CUs kept free of the C(t)/histogram kernels for the latency-bound fit kernels (CU-masked stream; 0 = no partition)')
     ap.add_argument('--fits-on-reserved-only', type=int, default=1, help='1/0: confine the fit kernels to the reserved CUs (strict partition)')
     ap.add_argument('--aux-cus', type=int, default=0, help='CUs set aside for the pack / histogram stream (multiple of 8; compute kernels are masked off them)')
@@ -117,7 +141,7 @@ def parse():
     ap.add_argument('--no-kernel-profile', action='store_true', help='skip the per-kernel alone / saturated timings after the timed region (the `kernels` entries then only carry in-pipeline durations)')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
     ap.add_argument('--all-ranks-on-device0', action='store_true', help='rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)')
-    ap.add_argument('--cpu-sample-vectors', type=int, default=8, help='vectors of the 1-thread reference-equivalent CPU sample')
+    ap.add_argument('--cpu-sample-vectors', type=int, default=4, help='vectors of the 1-thread reference-equivalent CPU sample (4: 10-15 s of CPU work, run BEFORE the GPU is initialised)')
     ap.add_argument('--cpu-allcore-vectors', type=int, default=64, help='vectors of the all-core / CPU-FFT samples (>= 64: not cache-resident)')
     return ap.parse_args()
 
@@ -136,7 +160,7 @@ def cpu_baseline(vecs_host, s, cfg, nv1, nvall):
     t0 = time.time()
     Ct, dCt = o.calculate_Ct_Palmer(v4, dtype=np.float32)          # same numpy calls as the reference, float32, 1 thread
     stages['ct_s'] = time.time() - t0
-    aniso = cfg == 3
+    aniso = cfg >= 3
     hist = edges = None
     if aniso:
         t0 = time.time()
@@ -233,11 +257,11 @@ def cli_wall(vecs_host, s, cfg, cpu):
         pref = os.path.join(tmp, 'rotdif')
         steps = [('calculate-Ct-from-traj', ['calculate-Ct-from-traj.py', '-s', 'reference.pdb', '-f', fn, '--dt', str(s['dt']), '--tau', str(s['tau_memory']),
                                              '-o', pref, '--vecHist', '--binary', '--vecAvg', '--S2', '--Ct'] +
-                  (['--vecRot', ' '.join('%.6f' % x for x in synth.Q_EXT)] if cfg == 3 else [])),
+                  (['--vecRot', ' '.join('%.6f' % x for x in synth.Q_EXT)] if cfg >= 3 else [])),
                  ('calculate-fitted-Ct', ['calculate-fitted-Ct.py', '-f', pref + '_Ctint.dat', '-o', pref]),
                  ('calculate-relaxations-from-Ct', ['calculate-relaxations-from-Ct.py', '-f', pref + '_fittedCt.dat', '-o', pref + '-600', '-F', '%ge6' % synth.FIELD_MHZ,
                                                     '--tu', 'ps', '--zeta', str(synth.ZETA)] +
-                  (['--distfn', pref + '_vecHistogram.npz', '-D', '%g %g' % (synth.DISO, synth.DANI)] if cfg == 3 else ['-D', '%g' % synth.DISO]))]
+                  (['--distfn', pref + '_vecHistogram.npz', '-D', '%g %g' % (synth.DISO, synth.DANI)] if cfg >= 3 else ['-D', '%g' % synth.DISO]))]
         total = 0.0
         for name, cmd in steps:
             t0 = time.time()
@@ -292,15 +316,30 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
 
-    cfg = 3 if args.workload == 'cfg3' else 2
+    cfg = {'cfg2': 2, 'cfg3': 3, 'cfg4': 4}[args.workload]
     s = synth.config_shapes(cfg)
-    V = args.vectors or s['V']
-    aniso = synth.DANI if cfg == 3 else None
-    q = synth.Q_EXT if cfg == 3 else None
+    aniso = synth.DANI if cfg >= 3 else None
+    q = synth.Q_EXT if cfg >= 3 else None
+    # ---- which vectors this rank owns ----
+    strong = args.scaling == 'strong'
+    if strong:
+        Vtot = args.vectors or s['V']
+        if Vtot % world:
+            sys.exit('bench.py: --scaling strong needs the %d vectors of the workload to divide by the %d ranks (equal all-gather pieces)' % (Vtot, world))
+        from spinrelax_amd.dist import shard_range
+        v0, V = shard_range(Vtot, rank, world)
+    else:
+        V = args.vectors or s['V']
+        Vtot, v0 = V * world, rank * V
     # ---- synthetic shard of this rank: generated on the host BEFORE the GPU is initialised (worker pool forks) ----
     t0 = time.time()
-    vecs_host = synth.synth_vectors_parallel(s['frames'], V, s['seed'], v0=rank * V)
+    vecs_host = synth.synth_vectors_parallel(s['frames'], V, s['seed'], v0=v0)
     gen_s = time.time() - t0
+    # ---- CPU baseline (rank 0, N = 1), also before the GPU is touched: it needs nothing from the device, and run first it
+    # does not sit between the GPU phases of the run ----
+    cpu_res = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu_res = cpu_baseline(vecs_host, s, cfg, min(args.cpu_sample_vectors, V), min(args.cpu_allcore_vectors, V))
 
     if args.all_ranks_on_device0:
         local = 0
@@ -452,6 +491,31 @@ def main():
         hist_ms = float(np.mean(hp)) if hp else None
         fp = _pairs(4, 5)                # grouped schedule: one merged launch per group, recorded on its first batch's entry
         fit_ms = None if (args.dev_skip_fits or not fp) else float(np.mean(fp))
+    # ---- one more (untimed) batch whose results are checksummed: C(t), dC(t), histogram and the R1/R2/NOE table of ALL the
+    # workload's vectors (all-gathered for N > 1) -- identical for every rank count and schedule (tests compare them) ----
+    last = {}
+
+    def keep(b):
+        last['Ct'], last['dCt'], last['hist'] = b.Ct.clone(), b.dCt.clone(), b.hist.clone()
+        last['relax'] = torch.from_numpy(np.ascontiguousarray(b.result['relax'])).to(dev)
+    with torch.cuda.stream(stream):
+        pipe.run(vecs, 1, None, keep, None)
+    torch.cuda.synchronize()
+    checksums = None
+    if last:
+        import hashlib
+        whole = {}
+        for name, tns in last.items():
+            tns = tns.contiguous()
+            if world > 1:
+                parts = [torch.empty_like(tns) for _ in range(world)]
+                dist.all_gather(parts, tns)
+                axis = {'Ct': 1, 'dCt': 1, 'hist': 0, 'relax': 1}[name]            # the vector / residue axis
+                tns = torch.cat(parts, dim=axis)
+            whole[name] = tns.cpu().numpy()
+        if rank == 0:
+            checksums = {k: hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()[:16] for k, v in whole.items()}
+            checksums['shapes'] = {k: list(v.shape) for k, v in whole.items()}
     best = pipe.fit_best
     nfev_by_order = {str(k): int(np.sum(v)) for k, v in pipe.nfev_last.items()}
     nfits_by_order = {str(k): int(np.size(v)) for k, v in pipe.nfev_last.items()}
@@ -550,11 +614,14 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = triples * world / (elapsed / args.steps)
+        triples_total = synth.exact_triples(s['R'], s['F'], Vtot)
+        value = triples_total / (elapsed / args.steps)
         use_fft = (args.ct_fft != 0) and 1024 < s['F'] + s['L'] <= 8192
         use_rfft = use_fft and args.ct_fft in (-1, 2) and s['F'] + s['L'] > 4096
         kname = 'k_ct_rfft' if use_rfft else ('k_ct_fft' if use_fft else 'k_ct_palmer')
         prof, prof_src = committed_profile() if cfg == 3 and V == 512 else ({}, None)
+        stale, build_id = profile_staleness() if prof else (None, None)
+        stale_txt = ' -- STALE: collected with library build %s, this run loaded build %s (re-run scripts/profile_round.sh)' % (PROFILE_BUILD_ID, build_id) if stale else ''
         N, R, L = s['N'], s['R'], s['L']
         kernels = {}
 
@@ -577,22 +644,26 @@ def main():
             pe = prof_entry(prof, name)
             e['traffic'] = pe['hbm_bytes_corrected'] if pe else None
             e['traffic_note'] = ('HBM bytes per launch (PMC 2*FETCH_SIZE + WRITE_SIZE) from the committed profile %s -- '
-                                 'not measured in this run' % prof_src) if pe else 'no committed PMC profile for this kernel / configuration'
+                                 'not measured in this run%s' % (prof_src, stale_txt)) if pe else 'no committed PMC profile for this kernel / configuration'
             e.update(extra)
             kernels[name] = e
             return e
 
         if use_fft:
             M, xflop = fft_exec_flop(s, V, use_rfft, bool(args.ct_traceless))
+            xflop_formula = float(xflop)
             pe = prof_entry(prof, kname)
             xsrc = 'formula (bench.py:fft_exec_flop)'
             if pe and pe.get('fp64_flop_per_launch'):
-                xflop, xsrc = pe['fp64_flop_per_launch'], 'PMC float64 instruction counts of the committed profile %s' % prof_src
+                xflop, xsrc = pe['fp64_flop_per_launch'], 'PMC float64 instruction counts of the committed profile %s%s' % (prof_src, stale_txt)
             form = ('Wiener-Khinchin on real input: %s float64 complex transforms of %d points (half the padded length), two workgroups per CU'
                     % ('5 (traceless components; the trace term from window sums) + 1' if (bool(args.ct_traceless) and M == 6144) else '6 + 1', M // 2)
                     if use_rfft else 'Wiener-Khinchin: 6 float64 autocorrelations by FFT, whole %d-point transform resident in LDS' % M)
             entry(kname, 'valu-fp64 (float64 vector FMA; latency- and LDS-exchange-limited)', xflop, 1e12, PEAK_FP64_TFLOPS, 'TFLOP/s',
                   ct_ms, alone.get('ct'), formulation=form, work_source=xsrc,
+                  work_per_launch_analytic=xflop_formula,
+                  work_analytic_note='operation count of the transforms, twiddle passes and spectrum steps (bench.py:fft_exec_flop); '
+                                     'the PMC count beside it is what the kernel executed',
                   algorithmic_bytes=12 * N * V + 8 * R * L * V,
                   note='in the pipeline the kernel is confined to %d of %d CUs' % (N_CU - reserve_used, N_CU))
             if alone.get('ct_direct'):
@@ -631,11 +702,19 @@ def main():
                     # duration includes the tail in which only the last-started expensive residues are still running
                     e['achieved_in_pipeline'] = fflop * group_used / (fit_ms * 1e-3) / 1e12
                     e['frac_in_pipeline'] = e['achieved_in_pipeline'] / PEAK_FP64_TFLOPS
+                e['work_note'] += stale_txt
             else:
                 e['achieved'] = e['frac'] = None
                 e['work_note'] = 'no committed float64-instruction PMC pass: flop rate not stated'
+            if fit_ms and sat:
+                # merged launch = bulk (the chip full of fits: saturated time per batch x batches) + tail (the last-started
+                # expensive residues finishing while nothing takes the freed slots; the group's histograms run there)
+                bulk = sat * group_used
+                e['in_pipeline_bulk_ms'] = bulk
+                e['in_pipeline_tail_ms'] = max(0.0, fit_ms - bulk)
+                e['in_pipeline_tail_frac'] = max(0.0, fit_ms - bulk) / fit_ms
             e['traffic'] = pe['hbm_bytes_corrected'] if pe else None
-            e['traffic_note'] = 'from the committed profile %s -- not measured in this run' % prof_src if pe else None
+            e['traffic_note'] = 'from the committed profile %s -- not measured in this run%s' % (prof_src, stale_txt) if pe else None
             e['algorithmic_bytes'] = 24 * V * L + 1024 * V
             kernels['k_order_search'] = e
         # the kernel that occupies most of the chip per batch
@@ -658,12 +737,23 @@ def main():
         prof_all, _ = committed_profile()
         step_flop = sum(float(v.get('fp64_flop_per_launch') or 0.0) * (2 if k.startswith('k_transpose') else 1) for k, v in prof_all.items()
                         if not k.startswith('k_fft_init'))
+        roofline['traffic_stale'] = stale
+        roofline['library_build_id'] = build_id
+        roofline['profile_build_id'] = PROFILE_BUILD_ID if prof else None
+        step_bytes = sum(float(v.get('hbm_bytes_corrected') or 0.0) * (2 if k.startswith('k_transpose') else 1) for k, v in prof_all.items()
+                         if not k.startswith('k_fft_init')) if prof else 0.0
+        if step_bytes > 0:
+            compulsory = 12.0 * s['frames'] * V + 16.0 * L * V + 8.0 * V * 2592
+            roofline['hbm_bytes_per_step'] = {'pmc': step_bytes, 'compulsory': compulsory, 'ratio': step_bytes / compulsory,
+                                              'GBps': step_bytes / (ms_per_step * 1e-3) / 1e9,
+                                              'note': 'sum over the kernels of a batch of the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE) against '
+                                                      'vectors in once + C(t), dC(t), histogram out; not measured in this run%s' % stale_txt}
         roofline['frac_alone'] = tk.get('frac_alone')
         roofline['launches_of_this_kernel_in_flight'] = (tk.get('in_pipeline_ms') or 0.0) / ms_per_step if ms_per_step else None
         roofline['chip'] = None if not (cfg == 3 and V == 512 and step_flop > 0) else {'fp64_flop_per_step': step_flop, 'TFLOPs': step_flop / (ms_per_step * 1e-3) / 1e12,
                             'frac': step_flop / (ms_per_step * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
                             'note': 'executed float64 flop of all kernels of a batch (committed PMC pass) over ms_per_step: the fraction of '
-                                    'the FP64 vector peak the pipeline as a whole sustains'}
+                                    'the FP64 vector peak the pipeline as a whole sustains' + stale_txt, 'stale': stale}
         res = {
             'metric': 'frame-vector-lag triples/s, C(t) + fit + R1/R2/NOE pipeline',
             'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -673,13 +763,15 @@ def main():
             'ms_per_step_steady': None if steady is None else steady * 1e3,
             'steady_note': 'one run of %d steps, fill and drain amortised; not the headline' % args.steady_steps,
             'spinup': {'seconds': spin_s, 'steps': spin_steps, 'note': 'untimed steps of the same pipeline before the warm-up steps (clock ramp of a fresh box)'},
-            'latency_ms': latency, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'latency_ms': latency, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f64 (C(t) by FFT on f32 inputs; histogram, fit, J(w), R1/R2/NOE)' if use_fft else 'f32 dot products / f64 accumulation (C(t)); f64 (histogram, fit, J(w), R1/R2/NOE)',
             'data': 'synthetic',
-            'config': {'workload': 'BASELINE cfg%d per GPU: %d frames x %d vectors, %d chunks x %d frames, %d lags, '
-                                   '%s, fits 2/3/5/7/9 params, 1 field' % (cfg, s['frames'], V, s['R'], s['F'], s['L'],
-                                                                           'axisymmetric D + q_ext + 72x36 histogram' if cfg == 3 else 'isotropic D'),
-                       'vectors_per_gpu': V, 'exact_triples_per_gpu': triples, 'sharding': 'vectors (no data-path collective; all-gather of results)',
+            'config': {'workload': 'BASELINE cfg%d%s: %d frames x %d vectors%s, %d chunks x %d frames, %d lags, '
+                                   '%s, fits 2/3/5/7/9 params, 1 field' % (cfg, '' if strong else ' per GPU', s['frames'], Vtot if strong else V,
+                                                                           (' in all, %d per GPU' % V) if strong and world > 1 else '', s['R'], s['F'], s['L'],
+                                                                           'axisymmetric D + q_ext + 72x36 histogram' if cfg >= 3 else 'isotropic D'),
+                       'vectors_total': Vtot, 'vectors_per_gpu': V, 'exact_triples_per_gpu': triples, 'exact_triples_total': triples_total,
+                       'sharding': 'contiguous vector ranges (spinrelax_amd/dist.py:shard_range; no data-path collective; all-gather of results)',
                        'schedule': ('grouped: pack / C(t) / chunk statistics%s of %d batches back to back, then ONE merged model-order search + '
                                     'relaxation launch over their %d residues (dispatched in a fixed pseudo-random order)%s; next group%s'
                                     % ('' if args.late_hist else ' / histogram', group_used, group_used * V,
@@ -696,10 +788,8 @@ def main():
             'setup': {'synth_s': gen_s},
             **({'INVALID': 'fits skipped (--dev-skip-fits)'} if args.dev_skip_fits else {}),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(vecs_host, s, cfg, min(args.cpu_sample_vectors, V), min(args.cpu_allcore_vectors, V))
-        else:
-            res['cpu_baseline'] = None
+        res['cpu_baseline'] = cpu_res            # measured before the GPU was initialised (rank 0, N = 1)
+        res['checksums'] = checksums
         if world == 1 and not args.no_cli_wall:
             res['cli_wall_s'] = cli_wall(vecs_host, s, cfg, res['cpu_baseline'])
         print(json.dumps(res))

@@ -37,10 +37,14 @@ extern "C" {
 
 typedef struct sr_ctx sr_ctx;
 
-#define SR_ABI_VERSION 6
+#define SR_ABI_VERSION 7
 
 /* ---- context, memory, timing ------------------------------------------------------------- */
 int          sr_abi_version(void);
+/* sha256 (hex, first 16 characters) of the sources and compiler flags this library was built from (spinrelax_amd/build.py
+ * computes it and compiles it in); "unknown" for a build that bypassed build.py.  bench.py compares it with the id stored
+ * in the committed PMC profile to tell whether per-launch counter figures still belong to the kernels that ran. */
+const char  *sr_build_id(void);
 const char  *sr_last_error(void);
 sr_ctx      *sr_create(int device);                 /* NULL on failure (see sr_last_error)        */
 void         sr_destroy(sr_ctx *);

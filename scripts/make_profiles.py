@@ -92,8 +92,51 @@ def hbm_json(raw, prefix, command):
     return out
 
 
+def issue_json(raw, build_id):
+    """Issue-side SQ counters (passes ISSUE1..3 of profile_round.sh), mean per launch and kernel.  SQ_* cycle counters are in
+    quad-cycles summed over the waves / SIMDs that counted them (MI355X_MICROARCH.md, cycle constants)."""
+    out = {}
+    names = {}
+    for p in ('ISSUE1', 'ISSUE2', 'ISSUE3'):
+        fs = glob.glob(os.path.join(raw, p, '**', '*counter_collection.csv'), recursive=True)
+        if not fs:
+            continue
+        t = pd.read_csv(max(fs, key=os.path.getmtime))
+        for c in sorted(set(t.Counter_Name)):
+            r = counters(os.path.join(raw, p), c)
+            if r is None:
+                continue
+            for k in r.index:
+                if skip(k):
+                    continue
+                out.setdefault(k, {})[c] = float(r.loc[k, 'mean'])
+                names[c] = 1
+    if not out:
+        return None
+    for k, v in out.items():
+        wc, busy = v.get('SQ_WAVE_CYCLES'), v.get('SQ_BUSY_CYCLES')
+        if wc:
+            for c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_LDS', 'SQ_ACTIVE_INST_VMEM',
+                      'SQ_ACTIVE_INST_SCA', 'SQ_WAIT_INST_LDS'):
+                if c in v:
+                    v[c + '_per_WAVE_CYCLES'] = v[c] / wc
+        if busy and 'SQ_ACTIVE_INST_VALU' in v:
+            # SQ_BUSY_CYCLES counts per SE-level SQ; VALU activity summed over waves: busy fraction of the SIMDs = active / (4 SIMDs x CU-busy)
+            if v.get('SQ_BUSY_CU_CYCLES'):
+                v['VALU_busy_of_SIMD_time'] = v['SQ_ACTIVE_INST_VALU'] / (4.0 * v['SQ_BUSY_CU_CYCLES'])
+    return {'build_id': build_id,
+            'command': 'rocprofv3 --pmc <8 SQ counters per pass> --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --depth 1 ... (scripts/profile_round.sh, passes ISSUE1-3)',
+            'note': 'mean per launch; *_per_WAVE_CYCLES = share of the waves\' lifetime (WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES); '
+                    'VALU_busy_of_SIMD_time = SQ_ACTIVE_INST_VALU / (4 x SQ_BUSY_CU_CYCLES)',
+            'kernels': out}
+
+
 def main():
     tag, raw = sys.argv[1], sys.argv[2]
+    try:
+        build_id = open(os.path.join(raw, 'build_id.txt')).read().strip()
+    except OSError:
+        build_id = None
     short_flags = '--no-cpu-baseline --no-kernel-profile --no-cli-wall --spinup-s 0 --repeats 1 --steady-steps 0'
     st = stats_csv(os.path.join(raw, 'stats'), os.path.join(PROF, '%s_bench_cfg3_kernel_stats.csv' % tag))
     sa = stats_csv(os.path.join(raw, 'stats_alone'), os.path.join(PROF, '%s_bench_cfg3_alone_kernel_stats.csv' % tag))
@@ -101,6 +144,7 @@ def main():
                             '--steps 3 --warmup 1 --depth 1 %s (separate passes; --depth 1 = one batch at a time: the counters are device-wide, '
                             'kernels of overlapping batches would be charged to each other)' % short_flags)
     if out is not None:
+        out['build_id'] = build_id
         # read requests by size: FETCH_SIZE = 64 B x RDREQ; a request is 32 B (RDREQ_32B) or 64 B, so
         # bytes actually requested = 32 * RDREQ_32B + 64 * (RDREQ - RDREQ_32B)
         rq = counters(os.path.join(raw, 'RDREQ'), 'TCC_EA0_RDREQ_sum')
@@ -117,6 +161,14 @@ def main():
                     out['kernels'][k]['rdreq_bytes_32_64'] = 32.0 * b + 64.0 * (a - b)
         with open(os.path.join(PROF, '%s_bench_cfg3_hbm_counters.json' % tag), 'w') as fp:
             json.dump(out, fp, indent=1)
+    iss = issue_json(raw, build_id)
+    if iss is not None:
+        with open(os.path.join(PROF, '%s_issue_counters.json' % tag), 'w') as fp:
+            json.dump(iss, fp, indent=1)
+        for k in ('k_ct_rfft', 'k_order_search'):
+            for kk, v in iss['kernels'].items():
+                if kk.startswith(k):
+                    print('issue', kk[:40], {c: round(x, 3) for c, x in v.items() if c.endswith('_per_WAVE_CYCLES') or c.startswith('VALU_busy')})
     # the direct kernel alone
     pal = {}
     for name, ctrs in (('palmer_FETCH', ['FETCH_SIZE']), ('palmer_WRITE', ['WRITE_SIZE']),
@@ -136,13 +188,15 @@ def main():
                                                v.get('SQ_INSTS_VALU_ADD_F32_mean_per_launch', 0.0))
     if pal:
         with open(os.path.join(PROF, '%s_ct_palmer_counters.json' % tag), 'w') as fp:
-            json.dump({'command': 'CT_FFT=0 rocprofv3 --pmc <one counter set per pass> --kernel-trace -- python3 scripts/dev/ct_time.py '
+            json.dump({'build_id': build_id,
+                       'command': 'CT_FFT=0 rocprofv3 --pmc <one counter set per pass> --kernel-trace -- python3 scripts/dev/ct_time.py '
                                   '(the direct kernel alone on the cfg3 planes: 24 chunks x 4096 frames x 512 vectors)',
                        'kernels': pal}, fp, indent=1)
     # cfg2
     s2 = stats_csv(os.path.join(raw, 'cfg2_stats'), os.path.join(PROF, '%s_bench_cfg2_kernel_stats.csv' % tag))
     o2 = hbm_json(raw, 'cfg2_', 'rocprofv3 --pmc ... --kernel-trace -- python3 bench.py --workload cfg2 --steps 3 --warmup 1 --depth 1 %s' % short_flags)
     if o2 is not None:
+        o2['build_id'] = build_id
         with open(os.path.join(PROF, '%s_bench_cfg2_counters.json' % tag), 'w') as fp:
             json.dump(o2, fp, indent=1)
     for label, t in (('in pipeline', st), ('alone (--depth 1)', sa), ('cfg2', s2)):

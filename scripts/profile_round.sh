@@ -12,6 +12,8 @@ out=$root/gpurun_out/${tag}prof
 mkdir -p $out
 cd /tmp
 export TMPDIR=/tmp
+# which library the figures belong to (spinrelax_amd/build.py:build_id, compiled into the library): stored in every JSON summary
+python3 -c "import sys; sys.path.insert(0, '$root'); from spinrelax_amd import _lib; print(_lib.load().sr_build_id().decode())" > $out/build_id.txt
 short="--no-cpu-baseline --no-kernel-profile --no-cli-wall --spinup-s 0 --repeats 1 --steady-steps 0"
 # (1) kernel statistics of the benchmark command the driver runs (the per-kernel alone / saturated launches after the
 #     timed region, the CPU baseline and the CLI chain are left out so that the averages are the in-pipeline durations)
@@ -28,6 +30,16 @@ echo "stats_alone done"
 for pass in "FETCH_SIZE:FETCH_SIZE" "WRITE_SIZE:WRITE_SIZE" \
             "FP64:SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" \
             "RDREQ:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
+    name=${pass%%:*}; ctr=${pass#*:}
+    timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$name -- \
+        python3 $root/bench.py --steps 3 --warmup 1 --depth 1 $short > $out/$name.log 2>&1 || echo "pass $name FAILED"
+    echo "pass $name done"
+done
+# (4b) issue-side counters of the two compute kernels (SQ block: 8 counters per pass), one batch at a time: how busy the VALU
+#      is, what the waves wait for, LDS activity -- the evidence behind "x % of the issue-limited ceiling" 
+for pass in "ISSUE1:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" \
+            "ISSUE2:SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM" \
+            "ISSUE3:SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
     name=${pass%%:*}; ctr=${pass#*:}
     timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$name -- \
         python3 $root/bench.py --steps 3 --warmup 1 --depth 1 $short > $out/$name.log 2>&1 || echo "pass $name FAILED"

@@ -19,6 +19,7 @@ class SpinRelaxHipError(RuntimeError):
 # name -> (restype, argtypes); mirrors include/spinrelax_hip.h one to one
 SIGNATURES = {
     'sr_abi_version': (c_int, []),
+    'sr_build_id': (c_char_p, []),
     'sr_last_error': (c_char_p, []),
     'sr_create': (c_void_p, [c_int]),
     'sr_destroy': (None, [c_void_p]),
@@ -128,7 +129,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 6
+ABI_VERSION = 7
 LIB_PATH = os.environ.get('SPINRELAX_HIP_LIB', LIB_PATH)      # alternative build of the same ABI
 
 

@@ -21,6 +21,21 @@ if os.environ.get('SR_FIT_DEV_FAST'):          # development: only the order-sea
     EXTRA['sr_fit.hip'] = EXTRA['sr_fit.hip'] + ['-DSR_FIT_DEV_FAST']
 
 
+def build_id():
+    """sha256 (first 16 hex characters) over every source, header and compiler flag that goes into the library: what
+    sr_build_id() of a library built by this module returns, and what scripts/make_profiles.py stores beside the PMC figures
+    of a profiling run (bench.py compares the two)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES) + ['sr_internal.h']:
+        with open(os.path.join(CSRC, name), 'rb') as fp:
+            h.update(name.encode() + b'\0' + fp.read())
+    with open(os.path.join(HERE, '..', 'include', 'spinrelax_hip.h'), 'rb') as fp:
+        h.update(b'spinrelax_hip.h\0' + fp.read())
+    h.update(repr((FLAGS, sorted(EXTRA.items()))).encode())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.isfile(target):
         return True
@@ -31,17 +46,29 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     hdrs = [os.path.join(CSRC, 'sr_internal.h'), os.path.join(HERE, '..', 'include', 'spinrelax_hip.h')]
     objs = []
+    bid = build_id()
+    idfile = os.path.join(CSRC, '.build_id')               # sr_core.o carries the id: rebuilt whenever the id changes
+    try:
+        with open(idfile) as fp:
+            id_changed = fp.read().strip() != bid
+    except OSError:
+        id_changed = True
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         if not os.path.isfile(s):
             raise FileNotFoundError(s)
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
-        if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + ['-c', s, '-o', o]
+        extra = EXTRA.get(src, [])
+        if src == 'sr_core.hip':
+            extra = extra + ['-DSR_BUILD_ID="%s"' % bid]
+        if force or _stale(o, [s] + hdrs) or (src == 'sr_core.hip' and id_changed):
+            cmd = [HIPCC] + FLAGS + extra + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)
         objs.append(o)
+    with open(idfile, 'w') as fp:
+        fp.write(bid + '\n')
     if force or _stale(LIB, objs):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:

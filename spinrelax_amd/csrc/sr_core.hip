@@ -66,6 +66,11 @@ extern "C" {
 
 int sr_abi_version(void) { return SR_ABI_VERSION; }
 
+#ifndef SR_BUILD_ID
+#define SR_BUILD_ID "unknown"
+#endif
+const char *sr_build_id(void) { return SR_BUILD_ID; }
+
 const char *sr_last_error(void) { return g_err; }
 
 sr_ctx *sr_create(int device)

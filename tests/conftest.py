@@ -4,6 +4,9 @@ import sys
 import numpy as np
 import pytest
 
+# before the HIP runtime starts: one hardware queue per stream of a pipeline (bench.py does the same; spinrelax_amd/pipeline.py)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '10')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'oracle')):
     if p not in sys.path:

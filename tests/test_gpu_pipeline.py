@@ -233,7 +233,10 @@ def test_signals_release_a_waiting_stream(setup):
     st = setup
     torch, ctx, dev = st['torch'], st['ctx'], st['dev']
     sig = ctx.signal_alloc()
-    a, b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    # the writer on a HIGH-priority stream: streams of one priority are multiplexed onto a few hardware queues (4 by default,
+    # assigned by use count), and a wait queued AHEAD of the write that releases it on the same hardware queue never ends.
+    # (The pipeline itself always submits the releasing launch before the wait.)  Priorities have queues of their own.
+    a, b = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev)
     x = torch.zeros(1 << 20, device=dev)
     torch.cuda.synchronize()
     ctx.set_stream(b.cuda_stream)
@@ -384,28 +387,44 @@ def test_full_size_batch_search_equals_host_driven_search():
     pipe.close()
 
 
-def test_bench_two_ranks_on_one_device(tmp_path):
-    """The N > 1 path of bench.py (per-rank vector shards, result all-gathers on their own stream, max-over-ranks
-    timing) rehearsed with two ranks sharing this GPU over gloo -- RCCL needs one GPU per rank."""
+def _run_bench(flags, ranks=1, port=29577, env=None):
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GPU_MAX_HW_QUEUES='6')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29577', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--vectors', '64',
-           '--backend', 'gloo', '--all-ranks-on-device0', '--no-cpu-baseline', '--depth', '3', '--reserve-cus', '0', '--spinup-s', '0', '--steady-steps', '0',
-           '--repeats', '2']
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    launcher = [sys.executable] if ranks == 1 else [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks),
+                                                    '--master-addr', '127.0.0.1', '--master-port', str(port)]
+    p = subprocess.run(launcher + [os.path.join(root, 'bench.py')] + flags, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                       env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
     assert len(lines) == 1                                   # rank 0 alone reports
-    j = json.loads(lines[0])
-    assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['steps'] == 4
-    assert j['config']['vectors_per_gpu'] == 64 and j['value'] > 0
-    assert j['fit']['residues'] == 64 and j['fit']['unfitted'] == 0
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_device(tmp_path):
+    """The N > 1 path of bench.py rehearsed with two ranks sharing this GPU over gloo (RCCL needs one GPU per rank):
+    STRONG scaling (the default: the workload's 64 vectors sharded 32 + 32 as spinrelax_amd/dist.py:shard_range cuts them,
+    result all-gathers on their own stream, max-over-ranks timing) must reproduce the one-rank run of the same 64 vectors --
+    the checksums of the gathered C(t), dC(t), histogram and R1/R2/NOE table are those of the single-process run, `value`
+    counts the workload's triples once -- and the weak mode keeps every rank on its own 64 vectors."""
+    common = ['--steps', '4', '--warmup', '1', '--vectors', '64', '--no-cpu-baseline', '--no-cli-wall', '--no-kernel-profile', '--spinup-s', '0',
+              '--steady-steps', '0', '--repeats', '2']
+    two = ['--gpus', '2', '--backend', 'gloo', '--all-ranks-on-device0']
+    one = _run_bench(['--gpus', '1'] + common)
+    j = _run_bench(two + common, ranks=2, env={'GPU_MAX_HW_QUEUES': '6'})
+    assert j['n_gpus'] == 2 and j['scaling'] == 'strong' and j['steps'] == 4
+    assert j['config']['vectors_total'] == 64 and j['config']['vectors_per_gpu'] == 32 and j['value'] > 0
+    assert j['config']['exact_triples_total'] == one['config']['exact_triples_total'] == 2 * j['config']['exact_triples_per_gpu']
+    assert abs(j['value'] - j['config']['exact_triples_total'] / (j['ms_per_step'] * 1e-3)) <= 1e-6 * j['value']
+    assert j['fit']['residues'] == 32 and j['fit']['unfitted'] == 0
     assert j['config']['schedule'].startswith('grouped') and j['config']['batches_per_group'] == 4   # the default schedule, with its gathers
+    assert one['scaling'] == 'strong' and one['config']['vectors_per_gpu'] == 64
+    assert j['checksums'] == one['checksums'] and j['checksums']['shapes']['relax'][1] == 64
+    w = _run_bench(two + common + ['--scaling', 'weak'], ranks=2, port=29579, env={'GPU_MAX_HW_QUEUES': '6'})
+    assert w['scaling'] == 'weak' and w['config']['vectors_per_gpu'] == 64 and w['config']['vectors_total'] == 128
+    assert w['checksums']['shapes']['relax'][1] == 128 and w['checksums'] != one['checksums']
 
 
 def test_bench_single_rank_under_torchrun_equals_plain_run():
@@ -453,6 +472,7 @@ def test_bench_json_contract():
     assert j['n_gpus'] == 1 and j['steps'] == 6 and j['warmup'] == 1 and j['higher_is_better'] is True
     assert j['unit'] == 'triples/s' and j['data'] == 'synthetic' and j['vs_baseline'] is None and 'workload' in j['config']
     assert abs(j['value'] - j['config']['exact_triples_per_gpu'] / (j['ms_per_step'] * 1e-3)) <= 1e-6 * j['value']
+    assert j['scaling'] == 'strong' and j['config']['vectors_total'] == j['config']['vectors_per_gpu'] == 512
     r = j['roofline']
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernel_ms', 'selection', 'direct_equivalent'):
         assert k in r, k

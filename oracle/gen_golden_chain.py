@@ -146,27 +146,36 @@ def gen_chain(tag, vecs, s, names, q=synth.Q_EXT, MHz=synth.FIELD_MHZ, extra=Non
 
 
 def main():
+    """python oracle/gen_golden_chain.py [case ...]  (no argument: every case; cases: cfg1 cfg2 cfg2full cfg3s cfg4s)"""
+    want = set(sys.argv[1:]) or {'cfg1', 'cfg2', 'cfg2full', 'cfg3s', 'cfg4s'}
     man_fn = os.path.join(GOLD, 'MANIFEST.json')
     with open(man_fn) as fp:
         manifest = json.load(fp)
     gg.manifest.clear()
     # cfg1: 32 residues
     s1 = synth.config_shapes(1)
-    gen_chain('cfg1', synth.synth_config(1), s1, list(range(2, 2 + s1['V'])))
+    if 'cfg1' in want:
+        gen_chain('cfg1', synth.synth_config(1), s1, list(range(2, 2 + s1['V'])))
     # cfg2: first 16 residues
     s2 = synth.config_shapes(2)
-    gen_chain('cfg2', synth.synth_config(2, nvec=16), s2, list(range(2, 18)))
+    if 'cfg2' in want:
+        gen_chain('cfg2', synth.synth_config(2, nvec=16), s2, list(range(2, 18)))
+    # cfg2, the WHOLE configuration: all 128 residues (BASELINE configs[1] end to end)
+    if 'cfg2full' in want:
+        gen_chain('cfg2full', synth.synth_config(2), s2, list(range(2, 2 + s2['V'])))
     # cfg3 slice: 8 residues
     s3 = synth.config_shapes(3)
-    gen_chain('cfg3s', synth.synth_config(3, nvec=8), s3, list(range(2, 10)))
+    if 'cfg3s' in want:
+        gen_chain('cfg3s', synth.synth_config(3, nvec=8), s3, list(range(2, 10)))
     # cfg4: 8 vectors of shard 3 (256 vectors per GPU, 8 GPUs)
-    s4 = synth.config_shapes(4)
-    per = s4['V'] // 8
-    v0 = CFG4_SHARD * per
-    cols = [v0 + i for i in CFG4_LOCAL]
-    vecs = np.concatenate([synth.synth_vectors(s4['frames'], 1, s4['seed'], v0=c) for c in cols], axis=1)
-    gen_chain('cfg4s', vecs, s4, [c + 2 for c in cols], extra=dict(shard=CFG4_SHARD, shard_v0=v0, shard_nV=per,
-                                                                   local_index=np.array(CFG4_LOCAL), Vtot=s4['V']))
+    if 'cfg4s' in want:
+        s4 = synth.config_shapes(4)
+        per = s4['V'] // 8
+        v0 = CFG4_SHARD * per
+        cols = [v0 + i for i in CFG4_LOCAL]
+        vecs = np.concatenate([synth.synth_vectors(s4['frames'], 1, s4['seed'], v0=c) for c in cols], axis=1)
+        gen_chain('cfg4s', vecs, s4, [c + 2 for c in cols], extra=dict(shard=CFG4_SHARD, shard_v0=v0, shard_nV=per,
+                                                                       local_index=np.array(CFG4_LOCAL), Vtot=s4['V']))
     manifest.update(gg.manifest)
     with open(man_fn, 'w') as fp:
         json.dump(manifest, fp, indent=1, sort_keys=True)

@@ -660,9 +660,6 @@ __global__ __launch_bounds__(256) void k_ct_fft(CtFftArgs a)
             }
             const int n = tid + 256 * n1;
             const bool in = n < F;
-#if defined(SR_FFT_EXP) && SR_FFT_EXP == 1
-            xr[n1] = in ? 0.001f * (float)(n & 255) : 0.f; yr[n1] = in ? 0.5f : 0.f; zr[n1] = in ? 0.002f * (float)(pair + tid) : 0.f;
-#else
             // unconditional loads from a clamped index + select: a conditional load becomes a branch, and a branch per
             // sample serialises the memory latency (that alone was 1.5 ms of 3.6 ms)
             const int nc = in ? n : 0;
@@ -670,7 +667,6 @@ __global__ __launch_bounds__(256) void k_ct_fft(CtFftArgs a)
             xr[n1] = in ? xv : 0.f;
             yr[n1] = in ? yv : 0.f;
             zr[n1] = in ? zv : 0.f;
-#endif
         }
         cplx sig[N1];
 #pragma unroll
@@ -939,16 +935,11 @@ template <bool TR> __device__ __forceinline__ double rfft_weight4(int c)
     return c == 0 ? 1.0 / 24.0 : (c == 1 ? 0.125 : (c == 5 ? 1.0 / 12.0 : 0.5));
 }
 
-// SR_RFFT_NUM_VGPR: register budget of the kernel below the 256 that two waves per SIMD allow.  (clang's amdgpu_num_vgpr counts
-// in units of TWO registers on gfx90a and later -- the backend doubles the value for the unified VGPR/AGPR file and silently
-// drops a request above the occupancy bound, so "240" must be written as 120.)
-#ifdef SR_RFFT_NUM_VGPR
-#define SR_RFFT_VGPR_ATTR __attribute__((amdgpu_num_vgpr(SR_RFFT_NUM_VGPR / 2)))
-#else
-#define SR_RFFT_VGPR_ATTR
-#endif
+// (A register budget below the 256 that two waves per SIMD allow -- amdgpu_num_vgpr, which counts in units of TWO registers on
+// gfx90a and later -- was tried to leave the bandwidth kernels room beside a C(t) + fit pair of waves: 240 / 232 / 224 VGPRs
+// cost 36-52 B of scratch in the transform loop, 0.93 -> 1.01 / 1.01 / 1.10 ms alone, no hiding gained)
 template <int N1, bool HALF, bool TR>
-__global__ __launch_bounds__(256, 2) SR_RFFT_VGPR_ATTR void k_ct_rfft(CtRfftArgs a)
+__global__ __launch_bounds__(256, 2) void k_ct_rfft(CtRfftArgs a)
 {
     extern __shared__ __align__(16) unsigned char fft_smem[];
     cplx *lds = reinterpret_cast<cplx *>(fft_smem);

@@ -49,12 +49,11 @@ __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 
 // Instruction-count reductions (bit-identical results unless noted; cfg3 benchmark batch, model-order search alone /
 // saturated per batch / whole pipeline step at 20 steps):
-//   SR_FIT_MARK=3 (default)  as 2, and exp(-t/tau) as one fused sequence (the device library's exp() without the selects a
-//                            non-positive argument cannot need):                                   8.95 / 0.836 / 3.40 ms (20 steps)
-//   SR_FIT_MARK=2            shared-divisor (Markstein) division for t/tau and for the forward-difference quotient, the
-//                            divisors and their reciprocals held in SGPRs (uni()), no branch:      9.25 / 0.868 / 3.45 ms
-//   SR_FIT_MARK=1            t/tau only                                                           9.39 / 0.905
-//   SR_FIT_MARK=0            IEEE divisions                                                       9.87 / 0.937 / 3.55
+//   exp(-t/tau) as one fused sequence (the device library's exp() without the selects a non-positive argument cannot
+//       need) on top of shared-divisor (Markstein) divisions for t/tau and for the forward-difference quotient, divisors
+//       and reciprocals held in SGPRs (uni()), no branch:                               8.95 / 0.836 / 3.40 ms (20 steps)
+//       (steps on the way, each a build switch at the time: Markstein for both quotients 9.25 / 0.868 / 3.45, for t/tau only
+//       9.39 / 0.905, IEEE divisions 9.87 / 0.937 / 3.55)
 //   SR_FIT_LEADER=1 (default) only the leader wave runs the n x n algebra and broadcasts the trial point through LDS: 2 % in
 //                            every measure once the reductions below were out of the way (6.69 / 0.728 against 6.84 / 0.746).
 //   SR_FIT_REDUCE_MANY=1 (default) the 54 lane sums of a Jacobian by the register-halving reduction of sr_internal.h
@@ -75,20 +74,11 @@ __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 #ifndef SR_FIT_LF_LDS
 #define SR_FIT_LF_LDS 1      // Cholesky factor in a per-wave LDS area instead of 90 VGPRs
 #endif
-#ifndef SR_FIT_MARK
-#define SR_FIT_MARK 3
-#endif
-// SR_FIT_LP=1: the trust-region sub-problem LANE-PARALLEL on the leader wave (lp_* below) instead of sequential on
-// workgroup-uniform values.  Measured (cfg3 batch, same box): saturated 0.719 -> 0.704 ms per batch, 23 -> 20.5 us per
-// evaluation of a nine-parameter fit, scratch 780 -> 424 B per lane, LDS operations per trial step 309 -> 18; every parity
-// test passes with it.  NOT the default: a 9 x 9 Cholesky and its triangular solves cost about as many instructions per
-// Levenberg parameter either way (742 against 550 + LDS traffic: readlanes and selects replace the loads), so the gain is
-// small -- and the fits of over-parameterised orders are chaotic in their last bits (tests/golden/*_fit_sens.npz): with this
-// build's rounding the ONE nine-parameter fit of the benchmark batch that never converges runs to the evaluation limit (900
-// evaluations, 18 ms) instead of stopping after ~390 (8 ms), which a 20-step run pays in full as pipeline drain.
-#ifndef SR_FIT_LP
-#define SR_FIT_LP 0
-#endif
+// Tried and dropped (round 3; the code is in the history, commit 1dd6a1d): the trust-region sub-problem LANE-PARALLEL on the
+// leader wave (one matrix row per lane, readlane / DPP row reductions) instead of sequential on workgroup-uniform values:
+// saturated 0.719 -> 0.704 ms per batch, scratch 780 -> 424 B per lane, every parity test passed -- but another summation
+// order in the 9-term dot products sends the ONE nine-parameter fit of the benchmark batch that never converges to the
+// evaluation limit (900 evaluations, 18 ms, instead of ~390 / 8 ms), which a 20-step run pays in full as pipeline drain.
 // Tried and dropped (round 3): parking the solver's workgroup-uniform n-vectors (x, g, d, g_h, the trial point) in a per-wave LDS
 // area across the model / Jacobian passes -- explicit stores before, volatile loads behind -- so that the register allocator
 // has nothing of them to spill: it spilled MORE (1 256 B per lane instead of 776, 216 scratch loads per solver iteration instead
@@ -118,15 +108,6 @@ __device__ __forceinline__ double div_shared(double a, double b, double r)
     q = fma(e, r, q);
     e = fma(-b, q, a);
     return fma(e, r, q);
-}
-// The quotient -t/tau only feeds exp(): when a*r is huge or infinite (tau at its lower bound, r = inf: the residual
-// would be NaN) exp() of it is 0 whatever its last bits, so the uncorrected product stands in -- a select, no branch
-// (a branch per division keeps the scheduler from interleaving the K independent exponentials of a point).
-__device__ __forceinline__ double div_shared_for_exp(double a, double b, double r)
-{
-    const double q0 = a * r;
-    const double q = div_shared(a, b, r);
-    return fabs(q0) <= 1e290 ? q : q0;
 }
 // exp(a / b) for a <= 0 < b with the quotient formed as above: the instruction sequence of the device library's
 // exp() (ROCm 7.2 ocml, read off its ISA: argument reduction by ln2 hi/lo, degree-11 polynomial in Horner form, ldexp)
@@ -183,15 +164,14 @@ struct Model {
     {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            tau_u[k] = SR_FIT_MARK >= 1 ? uni(x[K + k]) : x[K + k];
-            rtau[k] = SR_FIT_MARK >= 1 ? uni(1.0 / x[K + k]) : 0.0;
+            tau_u[k] = uni(x[K + k]);
+            rtau[k] = uni(1.0 / x[K + k]);
         }
     }
     __device__ static __forceinline__ void exps(const double *tau_u, const double *rtau, double t, double *e)
     {
 #pragma unroll
-        for (int k = 0; k < K; ++k) e[k] = SR_FIT_MARK >= 3 ? exp_neg_quotient(-1.0 * t, tau_u[k], rtau[k])
-                                                       : exp(SR_FIT_MARK >= 1 ? div_shared_for_exp(-1.0 * t, tau_u[k], rtau[k]) : (-1.0 * t) / tau_u[k]);
+        for (int k = 0; k < K; ++k) e[k] = exp_neg_quotient(-1.0 * t, tau_u[k], rtau[k]);
     }
     __device__ static __forceinline__ double value(const double *x, const double *e)
     {
@@ -525,275 +505,6 @@ __device__ __forceinline__ void strictly_feasible(double *x, const double *lb, c
     }
 }
 
-// ==================================================================================================================
-// The same algebra LANE-PARALLEL (SR_FIT_LP=1, default): element i of an n-vector lives in lane i of the leader wave
-// (i < N <= 11: one DPP row), row i of an n x n matrix in lane i's registers.  A workgroup-uniform double costs a whole
-// VGPR pair per lane for one number: the sequential form above needs B, the Cholesky factor and a dozen n-vectors as
-// uniform arrays -- ~450 registers, which is why they had been moved to LDS (~300 LDS operations and ~210 waits per trial
-// step) and still left 45 scratch accesses per step.  Here a vector is ONE register pair and a matrix N of them: the whole
-// sub-problem (B, both triangular factors, every work vector) is ~80 VGPRs, touches neither LDS nor scratch, and the
-// O(n^2) parts (quadratic forms, step-to-bound divisions, feasibility fix-ups) shrink to O(n) instructions.
-//   lp_get(v, j)      element j as a uniform value (two v_readlane)
-//   lp_row_sum / max  reduction over the row by four DPP steps; lanes >= N must hold the neutral element
-// Cholesky is right-looking with rows in lanes: column j of L appears one element per lane; the update of the trailing
-// rows uses L[k][j] as a uniform value (readlane), and the same value, stored by lane j, builds row j of U = L^T, so that
-// both triangular solves are column sweeps (forward with L rows, backward with U rows).  The factor and the forward solve
-// round exactly like cholN / fwdN (same operation order per element); the backward solve and the dot products add in
-// another order (lane tree instead of a chain), so fits move in their last bits against the sequential build.
-// ==================================================================================================================
-__device__ __forceinline__ double lp_get(double v, int j) { return sr_readlane_f64(v, j); }
-__device__ __forceinline__ double lp_row_sum(double v)
-{
-    v += sr_dpp_f64(v, 0);
-    v += sr_dpp_f64(v, 1);
-    v += sr_dpp_f64(v, 2);
-    v += sr_dpp_f64(v, 3);
-    return sr_readlane_f64(v, 0);
-}
-__device__ __forceinline__ double lp_row_max(double v)
-{
-    v = fmax(v, sr_dpp_f64(v, 0));
-    v = fmax(v, sr_dpp_f64(v, 1));
-    v = fmax(v, sr_dpp_f64(v, 2));
-    v = fmax(v, sr_dpp_f64(v, 3));
-    return sr_readlane_f64(v, 0);
-}
-__device__ __forceinline__ double lp_row_min(double v)
-{
-    v = fmin(v, sr_dpp_f64(v, 0));
-    v = fmin(v, sr_dpp_f64(v, 1));
-    v = fmin(v, sr_dpp_f64(v, 2));
-    v = fmin(v, sr_dpp_f64(v, 3));
-    return sr_readlane_f64(v, 0);
-}
-// lane vector from a workgroup-uniform array
-template <int N>
-__device__ __forceinline__ double lp_from_uniform(const double *u, int lane)
-{
-    double v = 0.0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) v = lane == i ? u[i] : v;
-    return v;
-}
-
-template <int N>
-struct LpFactor {
-    double Lr[N];       // lane i: L[i][j], j < i
-    double Ur[N];       // lane i: U[i][k] = L[k][i], k > i
-    double invl;        // lane i: 1 / L[i][i]
-};
-
-// Cholesky of (B + alpha I), B's row i in lane i (Brow[j] = B[i][j]); false when a pivot is not positive
-template <int N>
-__device__ __forceinline__ bool lp_chol(const double *Brow, double alpha, LpFactor<N> &F, double &lmin2, int lane)
-{
-    double S[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        S[j] = Brow[j] + (lane == j ? alpha : 0.0);
-        F.Lr[j] = 0.0;
-        F.Ur[j] = 0.0;
-    }
-    bool ok = true;
-    lmin2 = 1e300;
-    F.invl = 0.0;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        double piv = lp_get(S[j], j);
-        if (!(piv > 0.0)) { ok = false; piv = 1.0; }
-        lmin2 = fmin(lmin2, piv);
-        const double inv = rsqrt(piv);
-        F.invl = lane == j ? inv : F.invl;
-        const double l = S[j] * inv;                     // lane i > j: L[i][j]
-        F.Lr[j] = l;
-#pragma unroll
-        for (int k = j + 1; k < N; ++k) {
-            const double lk = lp_get(l, k);              // L[k][j]
-            S[k] = fma(-l, lk, S[k]);
-            F.Ur[k] = lane == j ? lk : F.Ur[k];
-        }
-    }
-    return ok;
-}
-// L z = b
-template <int N>
-__device__ __forceinline__ double lp_fwd(const LpFactor<N> &F, double b, int lane)
-{
-    double r = b, z = 0.0;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const double zj = lp_get(r * F.invl, j);
-        z = lane == j ? zj : z;
-        r = fma(-F.Lr[j], zj, r);
-    }
-    return z;
-}
-// L^T p = z
-template <int N>
-__device__ __forceinline__ double lp_bwd(const LpFactor<N> &F, double zv, int lane)
-{
-    double r = zv, p = 0.0;
-#pragma unroll
-    for (int j = N - 1; j >= 0; --j) {
-        const double pj = lp_get(r * F.invl, j);
-        p = lane == j ? pj : p;
-        r = fma(-F.Ur[j], pj, r);
-    }
-    return p;
-}
-// y = B s (lane i: sum_j B[i][j] s_j)
-template <int N>
-__device__ __forceinline__ double lp_matvec(const double *Brow, double sv)
-{
-    double y = 0.0;
-#pragma unroll
-    for (int j = 0; j < N; ++j) y = fma(Brow[j], lp_get(sv, j), y);
-    return y;
-}
-template <int N>
-__device__ __forceinline__ double lp_quad(const double *Brow, double sv) { return lp_row_sum(sv * lp_matvec<N>(Brow, sv)); }
-
-template <int N>
-__device__ __forceinline__ void lp_phi(const LpFactor<N> &F, double g, double Delta, double &p, double &phi, double &phi_prime, int lane)
-{
-    const double z = lp_fwd<N>(F, g, lane);
-    p = -lp_bwd<N>(F, z, lane);
-    const double q = lp_fwd<N>(F, p, lane);
-    const double pn = sqrt(lp_row_sum(p * p));
-    phi = pn - Delta;
-    phi_prime = -lp_row_sum(q * q) / pn;
-}
-
-// common.py:solve_lsq_trust_region (see solve_tr)
-template <int N>
-__device__ __forceinline__ void lp_solve_tr(const double *Brow, double Bdiag, double g, int m, double Delta, double &alpha, double &p,
-                                            int lane)
-{
-    LpFactor<N> F;
-    double lmin2;
-    bool full_rank = lp_chol<N>(Brow, 0.0, F, lmin2, lane);
-    if (full_rank) {
-        const double dmax = lp_row_max(Bdiag);
-        const double thr = kEPS * (double)m;
-        if (!(lmin2 > thr * thr * dmax)) full_rank = false;
-    }
-    double alpha_upper = sqrt(lp_row_sum(g * g)) / Delta;
-    double alpha_lower = 0.0;
-    if (full_rank) {
-        double phi, phip;
-        lp_phi<N>(F, g, Delta, p, phi, phip, lane);
-        if (phi <= 0.0) { alpha = 0.0; return; }
-        alpha_lower = -phi / phip;
-    }
-    if (!full_rank && alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
-    for (int it = 0; it < 10; ++it) {
-        if (alpha < alpha_lower || alpha > alpha_upper) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
-        double phi, phip;
-        lp_chol<N>(Brow, alpha, F, lmin2, lane);
-        lp_phi<N>(F, g, Delta, p, phi, phip, lane);
-        if (phi < 0) alpha_upper = alpha;
-        const double ratio = phi / phip;
-        alpha_lower = fmax(alpha_lower, alpha - ratio);
-        alpha -= (phi + Delta) * ratio / Delta;
-        if (fabs(phi) < 0.01 * Delta) break;
-    }
-    lp_chol<N>(Brow, alpha, F, lmin2, lane);
-    p = lp_bwd<N>(F, lp_fwd<N>(F, g, lane), lane);
-    const double sc = -Delta / sqrt(lp_row_sum(p * p));
-    p *= sc;
-}
-
-// common.py:step_size_to_bound; lanes >= N hold s = 0 (step infinity, no hit)
-__device__ __forceinline__ double lp_step_to_bound(double x, double sv, double lb, double ub, int &hit)
-{
-    double st = INFINITY;
-    if (sv != 0.0) st = fmax((lb - x) / sv, (ub - x) / sv);
-    const double mn = lp_row_min(st);
-    hit = (st == mn) ? (sv > 0 ? 1 : (sv < 0 ? -1 : 0)) : 0;
-    return mn;
-}
-
-// trf.py:select_step, lane vectors throughout (x, p, p_h, d, lb, ub: element i in lane i; zero in lanes >= N)
-template <int N>
-__device__ __forceinline__ void lp_select_step(double x, const double *Brow, double g_h, double p, double p_h, double d, double Delta,
-                                               double lb, double ub, double theta, double &step, double &step_h, double &predicted,
-                                               int lane)
-{
-    const bool on = lane < N;
-    {
-        const double xn = x + p;
-        const bool in_i = !on || ((xn >= lb) && (xn <= ub));
-        if (lp_row_min(in_i ? 1.0 : 0.0) > 0.5) {
-            predicted = -(0.5 * lp_quad<N>(Brow, p_h) + lp_row_sum(g_h * p_h));
-            step = p;
-            step_h = p_h;
-            return;
-        }
-    }
-    int hit;
-    const double p_stride = lp_step_to_bound(x, p, lb, ub, hit);
-    double r_h = hit != 0 ? -p_h : p_h;
-    double r = d * r_h;
-    p *= p_stride;
-    p_h *= p_stride;
-    const double xb = x + p;
-    double to_tr;
-    {
-        const double a = lp_row_sum(r_h * r_h), b = lp_row_sum(p_h * r_h), c = lp_row_sum(p_h * p_h) - Delta * Delta;
-        const double dd = sqrt(b * b - a * c);
-        const double q = -(b + copysign(dd, b));
-        const double t1 = q / a, t2 = c / q;
-        to_tr = t1 < t2 ? t2 : t1;
-    }
-    int hit2;
-    const double to_bound = lp_step_to_bound(xb, r, lb, ub, hit2);
-    double r_stride = fmin(to_bound, to_tr), r_stride_l, r_stride_u;
-    if (r_stride > 0) {
-        r_stride_l = (1 - theta) * p_stride / r_stride;
-        r_stride_u = (r_stride == to_bound) ? theta * to_bound : to_tr;
-    } else {
-        r_stride_l = 0;
-        r_stride_u = -1;
-    }
-    double r_value;
-    if (r_stride_l <= r_stride_u) {
-        const double Br = lp_matvec<N>(Brow, r_h);
-        const double a = 0.5 * lp_row_sum(r_h * Br);
-        const double b = lp_row_sum(g_h * r_h) + lp_row_sum(p_h * Br);
-        const double c = 0.5 * lp_quad<N>(Brow, p_h) + lp_row_sum(g_h * p_h);
-        min_quad_1d(a, b, r_stride_l, r_stride_u, c, r_stride, r_value);
-        r_h = r_h * r_stride + p_h;
-        r = r_h * d;
-    } else {
-        r_value = INFINITY;
-    }
-    p *= theta;
-    p_h *= theta;
-    const double p_value = 0.5 * lp_quad<N>(Brow, p_h) + lp_row_sum(g_h * p_h);
-
-    double ag_h = -g_h, ag = d * ag_h;
-    const double to_tr2 = Delta / sqrt(lp_row_sum(ag_h * ag_h));
-    int hit3;
-    const double to_bound2 = lp_step_to_bound(x, ag, lb, ub, hit3);
-    double ag_stride = (to_bound2 < to_tr2) ? theta * to_bound2 : to_tr2;
-    double ag_value;
-    {
-        const double a = 0.5 * lp_quad<N>(Brow, ag_h);
-        const double b = lp_row_sum(g_h * ag_h);
-        min_quad_1d(a, b, 0.0, ag_stride, 0.0, ag_stride, ag_value);
-    }
-    ag_h *= ag_stride;
-    ag *= ag_stride;
-
-    if (p_value < r_value && p_value < ag_value) {
-        step = p; step_h = p_h; predicted = -p_value;
-    } else if (r_value < p_value && r_value < ag_value) {
-        step = r; step_h = r_h; predicted = -r_value;
-    } else {
-        step = ag; step_h = ag_h; predicted = -ag_value;
-    }
-}
-
 extern __shared__ __align__(16) double fit_smem[];
 
 // Per-residue data access.  LDS = true: t, y and the weights 1/sigma of the residue live in LDS for the whole
@@ -928,14 +639,15 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
         if (!fitting) hi = (ud >= ld) ? ud : -ld;
         h[i] = hi;
         dx[i] = (x[i] + hi) - x[i];
-        if (SR_FIT_MARK >= 2) { dx[i] = uni(dx[i]); rdx[i] = uni(1.0 / dx[i]); }
+        dx[i] = uni(dx[i]);
+        rdx[i] = uni(1.0 / dx[i]);
     }
     double tau_u[K > 0 ? K : 1], rtau[K > 0 ? K : 1], tauh_u[K > 0 ? K : 1], rtau_h[K > 0 ? K : 1];
     M::recips(x, tau_u, rtau);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        tauh_u[k] = SR_FIT_MARK >= 1 ? uni(x[K + k] + h[K + k]) : 0.0;
-        rtau_h[k] = SR_FIT_MARK >= 1 ? uni(1.0 / (x[K + k] + h[K + k])) : 0.0;
+        tauh_u[k] = uni(x[K + k] + h[K + k]);
+        rtau_h[k] = uni(1.0 / (x[K + k] + h[K + k]));
     }
     double acc[NT + N];                       // J^T J (packed) followed by J^T f: reduced together below
     double *Aacc = acc, *gacc = acc + NT;
@@ -960,14 +672,13 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
 #pragma unroll
                 for (int k = 0; k < K; ++k) ei[k] = e[k];
                 if (i >= K && i < 2 * K)
-                    ei[i - K] = SR_FIT_MARK >= 3 ? exp_neg_quotient(-1.0 * tl, tauh_u[i - K], rtau_h[i - K])
-                                                   : exp(SR_FIT_MARK >= 1 ? div_shared_for_exp(-1.0 * tl, tauh_u[i - K], rtau_h[i - K]) : (-1.0 * tl) / xi[i]);
+                    ei[i - K] = exp_neg_quotient(-1.0 * tl, tauh_u[i - K], rtau_h[i - K]);
                 double fi;
                 {
 #pragma clang fp contract(off)
                     fi = w * (M::value(xi, ei) - yl);
                 }
-                Jr[i] = SR_FIT_MARK >= 2 ? div_shared(fi - f0, dx[i], rdx[i]) : (fi - f0) / dx[i];
+                Jr[i] = div_shared(fi - f0, dx[i], rdx[i]);
             }
         } else {
 #pragma unroll
@@ -1109,32 +820,6 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
                 // (J^T J, B, the Cholesky factor) lives in LDS, not in VGPRs; moving d and g_h there as well did not pay.
                 // (SR_FIT_LEADER=1: only the leader wave solves it and broadcasts the trial point.)
                 const double theta = fmax(0.995, 1 - g_norm);
-#if SR_FIT_LP
-                // lane vectors of the leader wave: x, lb, ub, d = sqrt(v), g_h = d g; B's row i in lane i (registers)
-                const int lane = T.tid & 63;
-                double Brow[N], Bdiag = 0.0, xl = 0.0, dl = 0.0, ghl = 0.0, lbl = 0.0, ubl = 1.0;
-#pragma unroll
-                for (int j = 0; j < N; ++j) Brow[j] = 0.0;
-                if (leader) {
-                    const bool on = lane < N;
-                    xl = lp_from_uniform<N>(x, lane);
-                    const double gl = lp_from_uniform<N>(g, lane);
-                    ubl = (lane >= K && lane < 2 * K) ? P.tau_max : 1.0;
-                    double vl = 1.0, dvl = 0.0;
-                    if (gl < 0) { vl = ubl - xl; dvl = -1.0; }
-                    if (gl > 0) { vl = xl - lbl; dvl = 1.0; }
-                    dl = on ? sqrt(vl) : 0.0;
-                    ghl = dl * gl;
-                    const int li = on ? lane : 0;
-#pragma unroll
-                    for (int j = 0; j < N; ++j) {
-                        const double aij = A[li >= j ? li * (li + 1) / 2 + j : j * (j + 1) / 2 + li];
-                        const double b = (aij * dl) * lp_get(dl, j) + (lane == j ? gl * dvl : 0.0);
-                        Brow[j] = on ? b : 0.0;
-                        Bdiag = lane == j ? Brow[j] : Bdiag;
-                    }
-                }
-#else
                 double d[N], g_h[N];
 #pragma unroll
                 for (int i = 0; i < N; ++i) { d[i] = sqrt(v[i]); g_h[i] = d[i] * g[i]; }
@@ -1146,32 +831,11 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
                         if (T.tid == 0) B[tri(i, j)] = b;
                     }
                 __syncthreads();
-#endif
 
                 double actual_reduction = -1.0, cost_new = cost;
                 double xn[N];
                 while (actual_reduction <= 0 && nfev < max_nfev) {
                     double predicted, step_h_norm, step_norm;
-#if SR_FIT_LP
-                    if (leader) {
-                        double pl_h, stepl, stepl_h;
-                        lp_solve_tr<N>(Brow, Bdiag, ghl, m, Delta, alpha, pl_h, lane);
-                        const double pl = dl * pl_h;
-                        lp_select_step<N>(xl, Brow, ghl, pl, pl_h, dl, Delta, lbl, ubl, theta, stepl, stepl_h, predicted, lane);
-                        double xnl = xl + stepl;
-                        strictly_feasible<1>(&xnl, &lbl, &ubl, 0.0);
-                        step_h_norm = sqrt(lp_row_sum(stepl_h * stepl_h));
-                        step_norm = sqrt(lp_row_sum(stepl * stepl));
-                        if (SR_FIT_LEADER && R::NTH > 64) {
-                            double *bc = T.bcast();
-                            if (lane < N) bc[lane] = xnl;
-                            if (lane == 0) { bc[N] = predicted; bc[N + 1] = step_h_norm; bc[N + 2] = step_norm; }
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < N; ++i) xn[i] = lp_get(xnl, i);
-                        }
-                    }
-#else
                     if (leader) {
                         double p_h[N], p[N], step[N], step_h[N];
                         solve_tr<N>(B, g_h, m, Delta, alpha, p_h, T.matLf());
@@ -1190,7 +854,6 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
                             bc[N] = predicted; bc[N + 1] = step_h_norm; bc[N + 2] = step_norm;
                         }
                     }
-#endif
                     if (SR_FIT_LEADER && R::NTH > 64) {
                         __syncthreads();
                         const double *bc = T.bcast();
@@ -1237,52 +900,6 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
 
     // ---- outputs: popt, pcov = (J^T J)^-1 * 2 cost / (m - n)  (curve_fit, _minpack_py.py:1040-1055), chi ----
     cov_ok = false;
-#if SR_FIT_LP
-    // by the leader wave, lane-parallel (J^T J's row i in lane i); the model-order search needs the diagonal on every thread
-    // (its quality flags are evaluated workgroup-uniformly): it travels through the broadcast area, read behind the
-    // barriers of the chi^2 sum below
-    constexpr bool kShare = DIAG && SR_FIT_LEADER && R::NTH > 64;
-    if (have_fit && m > N && leader) {
-        const int lane = T.tid & 63;
-        const bool on = lane < N;
-        const int li = on ? lane : 0;
-        double Arow[N], Adiag = 0.0;
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const double aij = A[li >= j ? li * (li + 1) / 2 + j : j * (j + 1) / 2 + li];
-            Arow[j] = on ? aij : 0.0;
-            Adiag = lane == j ? Arow[j] : Adiag;
-        }
-        LpFactor<N> F;
-        double lmin2;
-        cov_ok = lp_chol<N>(Arow, 0.0, F, lmin2, lane);
-        if (cov_ok) {
-            // conditioning guard equivalent to scipy's singular-value cut eps*max(m,n)*s_max
-            const double dmax = lp_row_max(Adiag);
-            const double thr = kEPS * (double)m;
-            if (!(lmin2 > thr * thr * dmax)) cov_ok = false;
-        }
-        if (cov_ok) {
-            const double s_sq = 2.0 * cost / (double)(m - N);
-#pragma unroll
-            for (int c = 0; c < N; ++c) {
-                const double col = lp_bwd<N>(F, lp_fwd<N>(F, lane == c ? 1.0 : 0.0, lane), lane);
-                if (DIAG) {
-                    pc[c] = lp_get(col, c) * s_sq;
-                } else {
-#pragma unroll
-                    for (int i = c; i < N; ++i) pc[tri(i, c)] = lp_get(col, i) * s_sq;
-                }
-            }
-        }
-        if (kShare && lane == 0) {
-            double *bc = T.bcast();
-#pragma unroll
-            for (int i = 0; i < N; ++i) bc[i] = cov_ok ? pc[i] : 0.0;
-            bc[N] = cov_ok ? 1.0 : 0.0;
-        }
-    }
-#else
     if (have_fit && m > N) {
         double Lf_regs[SR_FIT_LF_LDS ? 1 : NT], inv[N], lmin2;
         double *Lf = SR_FIT_LF_LDS ? T.matLf() : Lf_regs;
@@ -1313,7 +930,6 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
             }
         }
     }
-#endif
     chi = INFINITY;
     if (have_fit) {
         // calc_chiSq, fitting_Ct_functions.py:272-276: mean((model - y)^2 / sigma)
@@ -1326,14 +942,6 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
         }
         T.template block_sums<1>(acc);
         chi = acc[0] / (double)T.L;
-#if SR_FIT_LP
-        if (DIAG && SR_FIT_LEADER && R::NTH > 64 && m > N) {
-            const double *bc = T.bcast();
-            cov_ok = bc[N] != 0.0;
-#pragma unroll
-            for (int i = 0; i < N; ++i) pc[i] = bc[i];
-        }
-#endif
     }
 }
 

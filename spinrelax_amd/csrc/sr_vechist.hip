@@ -230,12 +230,7 @@ constexpr int kRangesPerWG = 4;
 constexpr int kListCap = 4096;       // parked samples a workgroup classifies densely; beyond that (pathological input:
                                      // every sample undecided) the collecting thread classifies them itself
 
-#ifdef SR_VECHIST_NUM_VGPR           // see SR_RFFT_NUM_VGPR in sr_ct.hip (the attribute counts in units of two registers)
-#define SR_VECHIST_VGPR_ATTR __attribute__((amdgpu_num_vgpr(SR_VECHIST_NUM_VGPR / 2)))
-#else
-#define SR_VECHIST_VGPR_ATTR
-#endif
-__global__ __launch_bounds__(256, 4) SR_VECHIST_VGPR_ATTR void k_vechist(VhArgs a)
+__global__ __launch_bounds__(256, 4) void k_vechist(VhArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double *edges = reinterpret_cast<double *>(smem);                 // nphi+1 + ncos+1

@@ -71,3 +71,22 @@ def files_equal_numeric(fa, fb, rtol=1e-6):
             if abs(fu - fv) > rtol * max(abs(fu), abs(fv)):
                 return False, 'line %d: %r vs %r' % (i + 1, x, y)
     return True, None
+
+
+def committed_tally(section, key, measured):
+    """Counts that are part of the parity contract (tests/golden/fit_trial_tallies.json, measured on MI355X and committed).
+    Returns the committed entry for (section, key); with SR_DUMP_TALLIES=<dir> the measured one is also written there
+    (how the committed file is refreshed after a deliberate change: scripts/collect_tallies.py merges the dumps)."""
+    import json
+    dump = os.environ.get('SR_DUMP_TALLIES')
+    if dump:
+        os.makedirs(dump, exist_ok=True)
+        with open(os.path.join(dump, 'tally__%s__%s.json' % (section, key)), 'w') as fp:
+            json.dump(measured, fp, indent=1)
+    try:
+        with open(os.path.join(GOLD, 'fit_trial_tallies.json')) as fp:
+            return json.load(fp)[section][key]
+    except (OSError, KeyError):
+        if dump:                      # first collection of a new entry: nothing committed to hold it to yet
+            return measured
+        raise

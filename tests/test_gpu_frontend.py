@@ -65,6 +65,79 @@ def test_superposition_vs_svd_kabsch(ctx, nframes, nvec, seed):
     assert np.allclose(q1, [[1, 0, 0, 0]] * 3, atol=1e-12)
 
 
+def _quat_to_matrix(quat):
+    w, x, y, z = quat.T
+    return np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
+                     np.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], -1),
+                     np.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1)], 1)
+
+
+def _fit_rmsd(R, xyz, ref_xyz, fit):
+    P = xyz[:, fit].astype(np.float64)
+    Q = ref_xyz[fit].astype(np.float64)
+    P = P - P.mean(axis=1, keepdims=True)
+    Q = Q - Q.mean(axis=0)
+    return np.sqrt((((np.einsum('nab,nib->nia', R, P) - Q[None]) ** 2).sum(-1)).mean(-1))
+
+
+def test_superposition_edge_cases_vs_svd_kabsch(ctx):
+    """The per-frame superposition (calculate-Ct-from-traj.py:466-467: MDTraj center_coordinates + superpose(ref, frame=0,
+    atom_indices=fit)) on the inputs where a least-squares rotation is delicate, against the oracle's SVD Kabsch (MDTraj is
+    absent from the image: this step stays "parity unpinned", DESIGN.md section 2 -- the oracle is the mathematics):
+      (a) a fit selection DIFFERENT from the vector atoms (--fitsel, :466): only atoms that carry no bond vector;
+      (b) MIRROR-IMAGE frames: the best orthogonal map is improper (det = -1), the best PROPER rotation is what superpose
+          applies (SVD with the determinant correction; Horn's quaternion is proper by construction);
+      (c) a PLANAR fit set (rank-2 covariance: one singular value 0) -- the rotation is still unique;
+      (d) a COLLINEAR fit set: the rotation about the line is undetermined, so what must agree is the residual (both are
+          optimal) and that the device returns a proper rotation and finite unit vectors."""
+    d = synth.synth_coordinates(300, 16, 41)
+    xyz, ref = d['xyz'], d['ref_xyz']
+    iX, iH = d['indexX'], d['indexH']
+    nat = xyz.shape[1]
+    extra = np.arange(2 * 16, nat, dtype=np.int32)                     # the scaffold atoms without bond vectors
+
+    def both(xyz_, ref_, fit_):
+        lab, fitv, quat = hostct.superpose_XHvecs(xyz_, ref_, fit_, iX, iH, ctx=ctx, want_quat=True)
+        want, R = o.superposed_XHvecs(xyz_, ref_, fit_, iX, iH)
+        Rq = _quat_to_matrix(quat)
+        assert np.max(np.abs(np.linalg.det(Rq) - 1)) < 1e-12 and np.all(np.isfinite(fitv))
+        assert np.max(np.abs(np.linalg.norm(fitv.astype(np.float64), axis=2) - 1)) < 2e-7
+        return fitv, want, Rq, R
+
+    # (a) fit on the extra atoms only
+    fitv, want, Rq, R = both(xyz, ref, extra)
+    assert np.max(np.abs(Rq - R)) < 1e-12 and np.max(np.abs(fitv - want)) < 2e-7
+    # ... and it is a different superposition from the all-heavy-atom one
+    _, _, Rall, _ = both(xyz, ref, d['fit_indices'])
+    assert np.max(np.abs(Rq - Rall)) > 1e-6
+    # (b) mirror images: x -> -x about the reference centroid, then the trajectory's own tumbling
+    mir = xyz.copy()
+    mir[..., 0] = -mir[..., 0]
+    fitv, want, Rq, R = both(mir, ref, d['fit_indices'])
+    assert np.max(np.abs(Rq - R)) < 1e-10 and np.max(np.abs(fitv - want)) < 2e-7
+    # the improper optimum would fit better: the proper one leaves a residual of the molecule's size
+    assert np.min(_fit_rmsd(R, mir, ref, d['fit_indices'])) > 0.1
+    # (c) planar fit set: flatten the extra atoms into the plane z = 1.5 in the reference and in every frame's body frame
+    ref_p = ref.copy()
+    ref_p[extra, 2] = 1.5
+    body = synth._rotate(np.concatenate([d['q'][:, :1], -d['q'][:, 1:]], axis=1)[:, None, :],
+                         xyz.astype(np.float64) - xyz[:, d['fit_indices']].astype(np.float64).mean(axis=1, keepdims=True))
+    body[:, extra, 2] = 0.0
+    xyz_p = (synth._rotate(d['q'][:, None, :], body) + 3.0).astype(np.float32)
+    fitv, want, Rq, R = both(xyz_p, ref_p, extra)
+    assert np.max(np.abs(Rq - R)) < 1e-9 and np.max(np.abs(fitv - want)) < 2e-7
+    # (d) collinear fit set: four atoms on a line
+    line = extra[:4]
+    ref_l = ref.copy()
+    ref_l[line] = np.array([[0.5, 1.0, 1.0], [1.0, 1.0, 1.0], [1.7, 1.0, 1.0], [2.5, 1.0, 1.0]], dtype=np.float32)
+    body_l = body.copy()
+    body_l[:, line] = (ref_l[line] - ref_l[line].mean(axis=0))[None]
+    xyz_l = (synth._rotate(d['q'][:, None, :], body_l) + 3.0).astype(np.float32)
+    fitv, want, Rq, R = both(xyz_l, ref_l, line)
+    ra, rb = _fit_rmsd(Rq, xyz_l, ref_l, line), _fit_rmsd(R, xyz_l, ref_l, line)
+    assert np.max(np.abs(ra - rb)) < 5e-7 and np.max(ra) < 1e-6          # both optimal (float32 coordinates: 1e-7 nm)
+
+
 def test_script_from_raw_coordinates_to_Ct(ctx, tmp_path):
     """calculate-Ct-from-traj.py fed raw coordinates: front end + C(t) on the GPU == the reference's C(t) function on the
     oracle's superposed vectors (float32 like the reference holds them)."""

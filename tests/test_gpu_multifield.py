@@ -123,8 +123,11 @@ def test_rscsa_device_search_walks_scipy_powell_path(tmp_path):
         dev.optimisation_loop_do_local_step()
         ch, cd = np.array(host.get_first_csa()), np.array(dev.get_first_csa())
         same = ch == cd
-        # x**2 on a numpy scalar goes through pow(): a last-bit difference in one evaluation may move the path
-        assert same.mean() >= 0.9, (scale, ch, cd)
+        # x**2 on a numpy scalar goes through pow(): a last-bit difference in one evaluation may move the path -- how many
+        # residues take the identical path is a committed count (all of them on MI355X), not a percentage
+        from conftest import committed_tally
+        want = committed_tally('rscsa_identical_paths', 'scale_%g' % scale, {'identical': int(same.sum()), 'of': int(same.size)})
+        assert same.size == want['of'] and same.sum() >= want['identical'], (scale, ch, cd)
         np.testing.assert_allclose(cd, ch, rtol=2e-3)
         assert cd[3] == start[3] * scale
         if same.all():

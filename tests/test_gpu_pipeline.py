@@ -334,14 +334,11 @@ def test_grouped_schedule_variants_equal_the_serial_pipeline(setup, variant):
         pipe.close()
 
 
-def test_full_size_batch_search_equals_host_driven_search():
-    """BASELINE cfg3, one full batch (100 000 frames x 512 vectors, L = 2048): the one-launch model-order search inside
-    the pipeline against the host-driven search that calls the single-order solver order by order -- identical
-    selection and bit-identical parameters / chi^2 for every residue and every attempted order (1 513 fits, up to
-    286 evaluations each).  Also the size-independent properties of the result."""
+@pytest.fixture(scope='module')
+def full_cfg3():
+    """BASELINE cfg3, one full batch (100 000 frames x 512 vectors, L = 2048) through the pipeline, once for the tests below"""
     import torch
     from spinrelax_amd import synth
-    from spinrelax_amd import fitting_Ct_functions as fitCt
     from spinrelax_amd.hip import Context
     from spinrelax_amd.pipeline import DevicePipeline
     s = synth.config_shapes(3)
@@ -354,9 +351,22 @@ def test_full_size_batch_search_equals_host_driven_search():
                           field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA, depth=1, stream=torch.cuda.Stream(device=dev))
     out = pipe.step(vecs).copy()
     sl = pipe.slots[0]
-    y, dy = sl.CtT.cpu().numpy(), sl.dCtT.cpu().numpy()
-    r = {k: v.copy() for k, v in sl.result.items()}
-    hist = sl.hist.cpu().numpy()
+    st = dict(s=s, V=V, vecs_host=vecs_host, ctx=ctx, pipe=pipe, out=out, y=sl.CtT.cpu().numpy(), dy=sl.dCtT.cpu().numpy(),
+              Ct=sl.Ct.cpu().numpy(), dCt=sl.dCt.cpu().numpy(), r={k: v.copy() for k, v in sl.result.items()}, hist=sl.hist.cpu().numpy())
+    del vecs
+    yield st
+    pipe.close()
+    ctx.close()
+
+
+def test_full_size_batch_search_equals_host_driven_search(full_cfg3):
+    """BASELINE cfg3, one full batch (100 000 frames x 512 vectors, L = 2048): the one-launch model-order search inside
+    the pipeline against the host-driven search that calls the single-order solver order by order -- identical
+    selection and bit-identical parameters / chi^2 for every residue and every attempted order (1 513 fits, up to
+    286 evaluations each).  Also the size-independent properties of the result."""
+    from spinrelax_amd import fitting_Ct_functions as fitCt
+    st = full_cfg3
+    s, V, ctx, pipe, out, y, dy, r, hist = (st[k] for k in ('s', 'V', 'ctx', 'pipe', 'out', 'y', 'dy', 'r', 'hist'))
     ctx.set_stream(0)
     search = fitCt.OrderSearchBatch(pipe.t_host, y, pipe.listDoG, 0.5)
     runner = fitCt.host_runner(pipe.t_host, y, dy, ctx=ctx)
@@ -384,7 +394,41 @@ def test_full_size_batch_search_equals_host_driven_search():
         assert np.all(np.diff(r['tau'][i, :r['K'][i]]) >= 0)
     assert np.all(hist.sum(axis=1) == s['N'])
     assert np.all(np.isfinite(out)) and np.all(out[0, :, 0, 0] > 0) and np.all(out[0, :, 1, 0] > out[0, :, 0, 0] * 0.5)
-    pipe.close()
+
+
+def test_full_size_cfg3_values_against_the_oracle(full_cfg3):
+    """The headline configuration compared VALUE BY VALUE, all 512 vectors (not a slice, not properties): C(t) and dC(t) of
+    the production path against the C oracle's float64 per-lag loop (oracle/ct_palmer_oracle.c =
+    calculate-Ct-from-traj.py:222-228 on every host core: 7.7e10 shifted products), the 512 spherical histograms against the
+    numpy restatement of rotate_vector_simd + xyz_to_rtp + histogramdd (transforms3d_supplement.py:270-296,
+    calculate-Ct-from-traj.py:585-626) count for count, and the (vectors, lags) copy the fit reads against the (lags, vectors)
+    one the files are written from."""
+    import ctypes
+    import os
+    import sr_oracle as o
+    from conftest import ROOT
+    from spinrelax_amd import synth
+    st = full_cfg3
+    s, V, vecs = st['s'], st['V'], st['vecs_host']
+    R, F, L, N = s['R'], s['F'], s['L'], s['N']
+    lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'libsr_oracle.so'))
+    v4 = np.ascontiguousarray(vecs[:N].reshape(R, F, V, 3))
+    Cr, dCr = np.empty((L, V)), np.empty((L, V))
+    rc = lib.sr_oracle_ct_palmer_f64(v4.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(R), ctypes.c_int64(F), ctypes.c_int64(V),
+                                     Cr.ctypes.data_as(ctypes.c_void_p), dCr.ctypes.data_as(ctypes.c_void_p), None)
+    assert rc == 0
+    del v4
+    eC = np.max(np.abs(st['Ct'] - Cr) / np.abs(Cr))
+    eD = np.max(np.abs(st['dCt'] - dCr) / np.abs(dCr))
+    print('\n[cfg3, all 512 vectors] C(t) max rel err %.2e, dC(t) %.2e (%d x %d values each)' % (eC, eD, L, V))
+    assert eC < 1e-12 and eD < 1e-9
+    assert np.array_equal(st['y'], st['Ct'].T) and np.array_equal(st['dy'], st['dCt'].T)
+    q = np.array(synth.Q_EXT)
+    hist = st['hist'].reshape(V, 72, 36)
+    for v0 in range(0, V, 64):                               # 64 vectors at a time: bounded host memory
+        href, _ = o.lambert_histogram(o.rotate_vector_simd(vecs[:N, v0:v0 + 64], q))
+        assert np.array_equal(hist[v0:v0 + 64], href), v0
+    assert hist.sum() == N * V
 
 
 def _run_bench(flags, ranks=1, port=29577, env=None):

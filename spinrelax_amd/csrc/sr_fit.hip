@@ -115,6 +115,12 @@ __device__ __forceinline__ double div_shared(double a, double b, double r)
 // place of the underflow select (which doubles as the guard for huge / infinite / NaN quotients).  Same bits as
 // exp(a / b) (scripts/dev/fit_dump.py: every fit of the fixtures ends on identical parameters); 23 instructions instead
 // of 11 + 23.
+extern __shared__ __align__(16) double fit_smem[];
+// Measured and dropped (round 4): a table-driven exp -- 2^(j/64) from a 64-entry LDS table, degree-4 polynomial on |t| <= ln2/128,
+// 5 float64 instructions fewer per exponential, below one ulp like this sequence but not the same bits: 0.743 -> 0.718 ms per
+// batch with the chip full (-3.4 %: the exponentials are half of the point loops' float64 work, the point loops a quarter of an
+// evaluation's time on the leader wave), every over-parameterised fit takes another path (order-9 evaluations 5 192 -> 5 205);
+// not worth re-measuring every parity tally for 1 % of a step.
 __device__ __forceinline__ double exp_neg_quotient(double a, double b, double r)
 {
     // quotients below -1100 (and the NaN a zero tau makes of the corrected quotient: maxNum returns the other operand)
@@ -504,8 +510,6 @@ __device__ __forceinline__ void strictly_feasible(double *x, const double *lb, c
         x[i] = xn;
     }
 }
-
-extern __shared__ __align__(16) double fit_smem[];
 
 // Per-residue data access.  LDS = true: t, y and the weights 1/sigma of the residue live in LDS for the whole
 // solve (3*L doubles after the reduction scratch) -- every model evaluation used to re-read them from L2/HBM

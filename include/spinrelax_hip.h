@@ -410,8 +410,6 @@ sr_sxydy *sr_text_open_sxydy(const char *path, const char *key, int nthreads);
 void      sr_text_close_sxydy(sr_sxydy *);
 int       sr_text_sxydy_info(const sr_sxydy *, int64_t *info6);
 int       sr_text_sxydy_get(const sr_sxydy *, double *x, double *y, double *dy, char *legends);
-/* host-to-host copy on nthreads threads (<= 0: 8); plain memcpy below 2 MiB */
-int       sr_host_copy_mt(void *dst, const void *src, size_t bytes, int nthreads);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,6 @@ SIGNATURES = {
     'sr_text_close_sxydy': (None, [c_void_p]),
     'sr_text_sxydy_info': (c_int, [c_void_p, c_void_p]),
     'sr_text_sxydy_get': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'sr_host_copy_mt': (c_int, [c_void_p, c_void_p, c_size_t, c_int]),
     'sr_signal_alloc': (c_void_p, [c_void_p]),
     'sr_signal_free': (c_int, [c_void_p, c_void_p]),
     'sr_stream_wait_signal': (c_int, [c_void_p, c_void_p, ctypes.c_uint32]),

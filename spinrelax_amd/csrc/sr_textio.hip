@@ -332,18 +332,3 @@ int sr_text_sxydy_get(const sr_sxydy *h, double *x, double *y, double *dy, char 
     }
     return 0;
 }
-
-/* a large host-to-host copy on several threads (the pipeline's pageable copies of a group's results out of the pinned
- * mirror: 10 MB that one thread moves in 1.7 ms, in the timed region behind the last kernel of a run) */
-int sr_host_copy_mt(void *dst, const void *src, size_t bytes, int nthreads)
-{
-    if (!dst || !src) { sr_set_error("sr_host_copy_mt: null pointer"); return -2; }
-    constexpr size_t kPiece = (size_t)1 << 20;
-    if (bytes < 2 * kPiece || nthreads == 1) { memcpy(dst, src, bytes); return 0; }
-    const int64_t pieces = (int64_t)((bytes + kPiece - 1) / kPiece);
-    parallel_for(pieces, nthreads > 0 ? nthreads : 8, [&](int64_t i) {
-        const size_t o = (size_t)i * kPiece, n = bytes - o < kPiece ? bytes - o : kPiece;
-        memcpy(static_cast<char *>(dst) + o, static_cast<const char *>(src) + o, n);
-    });
-    return 0;
-}

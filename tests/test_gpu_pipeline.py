@@ -431,6 +431,50 @@ def test_full_size_cfg3_values_against_the_oracle(full_cfg3):
     assert hist.sum() == N * V
 
 
+def test_full_size_cfg3_table_against_the_oracle_chain(full_cfg3, tmp_path):
+    """The rest of the headline configuration value by value: for ALL 512 residues the oracle runs the reference's chain on the
+    C(t) the device produced -- optimised_curve_fitting through scipy (fitting_Ct_functions.py:278-345), zeta scaling, J(w) and
+    R1 / R2 / NOE / rho over the 2 592 histogram bins (calculate-relaxations-from-Ct.py:125-191, 747-750) -- and the pipeline's
+    model selection and table are compared with it residue by residue.  Counts are committed numbers (tests/golden/
+    fit_trial_tallies.json): how many residues select the oracle's order, how many of the table's rows are within 1e-6."""
+    import sr_oracle as o
+    from conftest import committed_tally
+    import oracle_workers
+    from spinrelax_amd import synth
+    st = full_cfg3
+    s, V, pipe, r = st['s'], st['V'], st['pipe'], st['r']
+    t = np.asarray(pipe.t_host[0], dtype=np.float64)
+    y, dy = st['y'], st['dy']
+    fits = oracle_workers.fit_all(t, y, dy, str(tmp_path), nproc=16)        # plain child processes: numpy + scipy, no GPU
+    assert len(fits) == V and all(f is not None for f in fits)
+    nP_ref = np.array([f[0] for f in fits])
+    nP_dev = np.array([pipe.listDoG[b] for b in r['best']])
+    same = nP_ref == nP_dev
+    # the table from the ORACLE's fitted parameters and the oracle's histogram weights
+    B0 = o.B0_from_Hz(synth.FIELD_MHZ * 1e6)
+    Dpar, Dperp = o.symmtop_from_iso(synth.DISO, synth.DANI)
+    hist = st['hist'].reshape(V, 72, 36)
+    edges = [np.linspace(-np.pi, np.pi, 73), np.linspace(-1.0, 1.0, 37)]
+    bv, w = o.convert_LambertCylindricalHist_to_vecs(hist, edges)
+    S2 = [synth.ZETA * f[1] for f in fits]
+    C = [synth.ZETA * np.asarray(f[2]) for f in fits]
+    tau = [np.asarray(f[3]) for f in fits]
+    ref = o.obtain_R1R2NOErho('rigid_symmtop', (Dpar, Dperp), B0, S2, C, tau, vecXH=[bv[i] for i in range(V)],
+                              weights=[w[i] for i in range(V)], cast32=False)                     # (4, V, 2)
+    dev = st['out'][0]                                                                            # (V, 4, 2)
+    rel = np.max(np.abs(dev[:, :3, 0] / ref[:3, :, 0].T - 1.0), axis=1)
+    chi_rel = np.abs(r['chi'] / np.array([f[4] for f in fits]) - 1.0)
+    got = dict(residues=int(V), same_order=int(same.sum()), within_1e6=int((rel < 1e-6).sum()),
+               same_order_within_1e6=int((rel[same] < 1e-6).sum()), chi_within_1e5=int((chi_rel[same] < 1e-5).sum()))
+    print('\n[cfg3, all 512 residues vs the oracle chain] %s; max rel (same order) %.2e, median %.2e; orders (device) %s'
+          % (got, rel[same].max(), np.median(rel), dict(zip(*np.unique(nP_dev, return_counts=True)))))
+    want = committed_tally('full_cfg3_chain', 'table', got)
+    assert got['residues'] == want['residues']
+    for k in ('same_order', 'within_1e6', 'same_order_within_1e6', 'chi_within_1e5'):
+        assert got[k] >= want[k], (k, got, want)
+    assert np.all(rel[same] < 2e-4)                 # the bound test_gpu_chain.py puts on ill-conditioned fits
+
+
 def _run_bench(flags, ranks=1, port=29577, env=None):
     import json
     import os

@@ -141,7 +141,7 @@ def parse():
     ap.add_argument('--no-kernel-profile', action='store_true', help='skip the per-kernel alone / saturated timings after the timed region (the `kernels` entries then only carry in-pipeline durations)')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
     ap.add_argument('--all-ranks-on-device0', action='store_true', help='rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)')
-    ap.add_argument('--cpu-sample-vectors', type=int, default=4, help='vectors of the 1-thread reference-equivalent CPU sample (4: 10-15 s of CPU work, run BEFORE the GPU is initialised)')
+    ap.add_argument('--cpu-sample-vectors', type=int, default=6, help='vectors of the 1-thread reference-equivalent CPU sample (6: about 12 s of CPU work, run BEFORE the GPU is initialised)')
     ap.add_argument('--cpu-allcore-vectors', type=int, default=64, help='vectors of the all-core / CPU-FFT samples (>= 64: not cache-resident)')
     return ap.parse_args()
 
@@ -661,9 +661,11 @@ def main():
                     if use_rfft else 'Wiener-Khinchin: 6 float64 autocorrelations by FFT, whole %d-point transform resident in LDS' % M)
             entry(kname, 'valu-fp64 (float64 vector FMA; latency- and LDS-exchange-limited)', xflop, 1e12, PEAK_FP64_TFLOPS, 'TFLOP/s',
                   ct_ms, alone.get('ct'), formulation=form, work_source=xsrc,
-                  work_per_launch_analytic=xflop_formula,
-                  work_analytic_note='operation count of the transforms, twiddle passes and spectrum steps (bench.py:fft_exec_flop); '
-                                     'the PMC count beside it is what the kernel executed',
+                  work_per_launch_textbook=xflop_formula, executed_over_textbook=float(xflop) / xflop_formula,
+                  work_textbook_note='textbook operation count of the same transforms (5 N log2 N per complex N-point transform, 6 flop '
+                                     'per twiddle, 24 per frequency of the spectrum step; bench.py:fft_exec_flop) -- an upper bound: the '
+                                     'radix-12 / 16 register transforms have trivial twiddles and the zero blocks of the padded input are pruned, '
+                                     'so the kernel executes less (work_per_launch, PMC)',
                   algorithmic_bytes=12 * N * V + 8 * R * L * V,
                   note='in the pipeline the kernel is confined to %d of %d CUs' % (N_CU - reserve_used, N_CU))
             if alone.get('ct_direct'):

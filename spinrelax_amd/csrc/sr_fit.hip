@@ -745,6 +745,15 @@ struct SolveParams {
     int max_nfev, jac_mode;
 };
 
+// Workgroup-uniform n-vectors of the solver in SGPRs (round 4).  x, the gradient g, the Coleman-Li scaling v / dv, d = sqrt(v) and
+// g_h = d g are the same in every lane; the compiler cannot know that and keeps them in VGPRs -- 2 per double, ~110 registers at
+// n = 9 that are live across the whole trust-region step and were its spill victims (42 scratch reloads per trial step, each a
+// round trip in the leader wave's dependent chain).  uni() (v_readfirstlane) hands them over as scalar registers, which a float64
+// VALU instruction takes as an operand: same values, same operations, bit-identical fits.  Measured on the cfg3 batch: scratch
+// 808 -> 596 B per lane, 42 -> 19 scratch reloads per trial step, a lone launch 6.56 -> 6.27 ms (20.4 instead of 21.4 us per
+// evaluation of the slowest residue), 0.710 -> 0.700 ms per batch with the chip full.  Going further (the scalars cost, Delta,
+// alpha, theta and x at the initial point as well) runs out of SGPRs: 102 in use, the overflow goes to VGPR lanes and the frame
+// grows again (644 B, 25 reloads).
 // curve_fit(...) of conduct_curve_fitting for the staged residue T, starting from p0 (registers).
 // Outputs: x (optimum), pc (packed covariance, valid when cov_ok), chi (calc_chiSq), status, nfev.
 // DIAG: pc receives only the N diagonal elements of the covariance (what the model-order search needs for its dP > P
@@ -809,9 +818,12 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
             while (true) {
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
+                    g[i] = uni(g[i]);
                     v[i] = 1.0; dv[i] = 0.0;
                     if (g[i] < 0) { v[i] = ub[i] - x[i]; dv[i] = -1.0; }
                     if (g[i] > 0) { v[i] = x[i] - lb[i]; dv[i] = 1.0; }
+                    v[i] = uni(v[i]);
+                    dv[i] = uni(dv[i]);
                 }
                 double g_norm = 0.0;
 #pragma unroll
@@ -826,7 +838,7 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
                 const double theta = fmax(0.995, 1 - g_norm);
                 double d[N], g_h[N];
 #pragma unroll
-                for (int i = 0; i < N; ++i) { d[i] = sqrt(v[i]); g_h[i] = d[i] * g[i]; }
+                for (int i = 0; i < N; ++i) { d[i] = uni(sqrt(v[i])); g_h[i] = uni(d[i] * g[i]); }
 #pragma unroll
                 for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -893,7 +905,7 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
                 }
                 if (actual_reduction > 0) {
 #pragma unroll
-                    for (int i = 0; i < N; ++i) x[i] = xn[i];
+                    for (int i = 0; i < N; ++i) x[i] = uni(xn[i]);
                     cost = cost_new;
                     eval_jac<N>(T, x, lb, ub, P.jac_mode, A, g);
                 }

@@ -131,6 +131,7 @@ def parse():
     ap.add_argument('--ct-fft', type=int, default=-1, help='kernel 1: 2 = real-input FFT (k_ct_rfft) where it applies, 1 = complex FFT (k_ct_fft), 0 = direct (k_ct_palmer); -1 = library default (2)')
     ap.add_argument('--ct-traceless', type=int, default=0, help='1: k_ct_rfft<12> with five transforms (traceless components; library option ct_traceless, default off)')
     ap.add_argument('--group', type=int, default=32, help='batches whose fits / relaxation run as ONE merged launch behind their C(t) kernels (GroupedPipeline; a run of K steps uses groups of min(K, group)); 1 = every batch launches its own fits (DevicePipeline, --depth of them in flight)')
+    ap.add_argument('--pack-cus', type=int, default=128, help='grouped schedule: CUs the pack stream is confined to (0 = all; the compute streams always have the whole chip)')
     ap.add_argument('--psum-buffers', type=int, default=3, help='grouped schedule: raw-sum buffers the C(t) launches rotate through')
     ap.add_argument('--late-hist', type=int, default=1, help='grouped schedule: 1 = the histograms of a group run in the tail of its merged fit launch (released by the signal the launch\'s last workgroup writes; the planes of group + 3 batches stay alive), 0 = beside the C(t) kernels')
     ap.add_argument('--no-group-overlap', action='store_true', help='grouped schedule: the next group\'s C(t) kernels wait for the merged fit launch (strict phases)')
@@ -368,7 +369,7 @@ def main():
     pkw = dict(q_rot=q, Diso=synth.DISO, aniso=aniso, field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA)
     grouped = args.group > 1 and args.depth > 1 and not args.reserve_cus and not args.aux_cus and not args.hist_on_main
     if grouped:
-        pipe = GroupedPipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], group=args.group, overlap=not args.no_group_overlap, psum_buffers=args.psum_buffers, late_hist=bool(args.late_hist),
+        pipe = GroupedPipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], group=args.group, overlap=not args.no_group_overlap, psum_buffers=args.psum_buffers, late_hist=bool(args.late_hist), pack_cus=args.pack_cus,
                                stream=torch.cuda.Stream(device=dev, priority=args.main_priority),
                                **({} if args.late_hist else {'plane_buffers': args.plane_buffers}), **pkw)
         pipe.permute = not args.no_permute
@@ -521,6 +522,7 @@ def main():
     nfits_by_order = {str(k): int(np.size(v)) for k, v in pipe.nfev_last.items()}
     nfev_step = nfev_timed / max(1, args.steps * max(1, args.repeats))
     depth_used, reserve_used = pipe.depth, pipe.reserve_cus
+    pack_cus_used = getattr(pipe, 'pack_cus', 0) or 256
     group_used = min(args.group, args.steps) if grouped else 1
     listDoG = pipe.listDoG
     del events, gbuf
@@ -780,7 +782,8 @@ def main():
                                        ', their histograms in the tail of that launch (released by a signal its last workgroup writes)' if args.late_hist else '',
                                        ' overlaps it' if not args.no_group_overlap else ' waits for it'))
                                    if grouped else 'per batch: every batch launches its own fits, %d batches in flight' % depth_used,
-                       'batches_per_group': group_used, 'batches_in_flight': group_used if grouped else depth_used, 'cus_reserved_for_fits': reserve_used},
+                       'batches_per_group': group_used, 'batches_in_flight': group_used if grouped else depth_used, 'cus_reserved_for_fits': reserve_used,
+                       'pack_stream_cus': pack_cus_used},
             'roofline': roofline,
             'kernels': kernels,
             'stages_alone_ms': {k: round(v, 4) for k, v in alone.items()},

@@ -123,7 +123,8 @@ class _Slot:
 class DevicePipeline:
     def __init__(self, ctx, device, frames, V, R, F, dt, q_rot=None, Diso=None, aniso=None, field_MHz=(600.133,),
                  zeta=0.890023, histBinX=72, listDoG=(2, 3, 5, 7, 9), csa=None, depth=1, stream=None, reserve_cus=0,
-                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None, hist_on_aux=True, v0=0, aux_cus=0, fit_priority=0, plane_buffers=3):
+                 fits_on_reserved_only=False, chiSqThreshold=0.5, q_orient=None, hist_on_aux=True, v0=0, aux_cus=0, fit_priority=0, plane_buffers=3,
+                 pack_cus=0):
         self.ctx = ctx
         self.dev = device
         self.frames, self.V, self.R, self.F, self.dt = frames, V, R, F, dt
@@ -189,6 +190,20 @@ class DevicePipeline:
         # critical path of two C(t) launches that overlap each other)
         self.NB = max(2, int(plane_buffers)) if self.depth > 1 else 1
         self.soa_bufs = [self.soa] + [torch.empty_like(self.soa) for _ in range(self.NB - 1)]
+        # `pack_cus`: the auxiliary stream (the pack kernel, per-batch histograms) confined to this many CUs while the compute
+        # streams keep the whole chip.  The pack is HBM-bound and hardly issues (83 % of its waves' lifetime parked); spread
+        # over all 256 CUs its waves sit beside every C(t) workgroup pair (16 + 2 x 248 VGPRs fill a SIMD exactly) and its
+        # bursts hit the memory system while those workgroups prefetch.  On 96-160 CUs it still streams as fast as it needs
+        # (0.33 ms in the pipeline either way) and half of the C(t) workgroups never meet it: steady state 2.13 -> 2.09 ms
+        # per step (same box, alternating runs, two rounds each; 64 CUs: 2.17, 32: 2.6; the chunk-statistics stream
+        # confined as well: no further change).  CU bit i belongs to XCD i % 8, so a prefix of 8 k bits is k CUs per XCD.
+        self.pack_cus = 0
+        if pack_cus and aux_words is None and self.depth > 1:
+            ncu = info['n_cu']
+            n = min(ncu, (int(pack_cus) + 7) // 8 * 8)
+            if n < ncu:
+                self.pack_cus = n
+                aux_words = self._mask_words(range(0, n), ncu)
         self.aux = (self._borrow(aux_words) if aux_words is not None else torch.cuda.Stream(device=device)) if self.depth > 1 else None
         self._packed_ev = [None] * self.NB
         self.hist_on_aux = hist_on_aux
@@ -748,6 +763,7 @@ class GroupedPipeline(DevicePipeline):
 
     def __init__(self, ctx, device, frames, V, R, F, dt, group=32, overlap=True, psum_buffers=3, late_hist=True, **kw):
         kw = dict(kw)
+        kw.setdefault('pack_cus', 128)                    # the pack stream on half of the CUs (DevicePipeline.__init__)
         kw['depth'] = max(2, int(psum_buffers))          # the base class's slots: only their raw-sum buffers are used (a rotating pool)
         self.late_hist = bool(late_hist)
         self.late_hist_note = None

@@ -798,7 +798,7 @@ class GroupedPipeline(DevicePipeline):
         E = len(self.fields)
         self.groups = [_Group(ctx, device, self.group, V, self.L, R, self.nbins, len(self.listDoG), Pmax, E,
                               torch.cuda.Stream(device=device)) for _ in range(2)]
-        self.hist_stream = torch.cuda.Stream(device=device) if self.late_hist else None
+        self.hist_stream = torch.cuda.Stream(device=device) if self.late_hist else None      # (confined to 64 / 128 / 192 CUs: slower, 2.40-2.76 ms per step)
         self._late = []
         self._hist_done_ev = [None] * self.NB           # late histograms: "the histogram that read this plane buffer has run"
         from .hip import SpinRelaxHipError

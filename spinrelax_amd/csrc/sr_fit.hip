@@ -593,18 +593,31 @@ struct Residue {
 };
 
 // cost = 0.5 f.f of the residuals f = w*(model - y); finite=false when any f is not finite
+// Point cache (one-exponential models, N <= 3): the exponentials and the residual of a thread's first kCacheCap points as
+// eval_f computed them.  A Jacobian is only ever evaluated at the point the last eval_f call was made at (the initial
+// point, or the trial point that has just been accepted), so eval_jac takes them from here instead of recomputing them --
+// the same values by construction.  2 x 8 doubles per thread; at N <= 3 the solver has the registers.
+constexpr int kCacheCap = 8;
+template <int N> constexpr bool fit_point_cache() { return N <= 3; }     // (N <= 5 measured: 48 more live registers, no gain)
+template <int N>
+struct PointCache {
+    static constexpr int K = N / 2;
+    double e[fit_point_cache<N>() ? kCacheCap * (K > 0 ? K : 1) : 1];
+    double f[fit_point_cache<N>() ? kCacheCap : 1];
+};
+
 template <int N, class R>
-__device__ __forceinline__ double eval_f(const R &T, const double *x, bool &finite)
+__device__ __forceinline__ double eval_f(const R &T, const double *x, bool &finite, PointCache<N> &pc)
 {
     constexpr int K = N / 2;
+    constexpr bool CACHE = fit_point_cache<N>();
     using M = Model<N>;
     const int tid = T.tid, L = T.L;
     constexpr int NTH = R::NTH;
     double acc = 0.0, bad = 0.0;
     double tau_u[K > 0 ? K : 1], rtau[K > 0 ? K : 1];
     M::recips(x, tau_u, rtau);
-    for (int l = tid; l < L; l += NTH) {
-        double e[K > 0 ? K : 1];
+    auto point = [&](int l, double *e) {
         M::exps(tau_u, rtau, T.ld_t(l), e);
         double f;
         {
@@ -612,6 +625,25 @@ __device__ __forceinline__ double eval_f(const R &T, const double *x, bool &fini
             f = T.ld_w(l) * (M::value(x, e) - T.ld_y(l));
         }
         if (!isfinite(f)) bad = 1.0; else acc = fma(f, f, acc);
+        return f;
+    };
+    int l0 = tid;
+    if (CACHE) {
+#pragma unroll
+        for (int j = 0; j < kCacheCap; ++j) {
+            const int l = tid + j * NTH;
+            if (l < L) {
+                double e[K > 0 ? K : 1];
+                pc.f[j] = point(l, e);
+#pragma unroll
+                for (int k = 0; k < K; ++k) pc.e[j * K + k] = e[k];
+            }
+        }
+        l0 = tid + kCacheCap * NTH;
+    }
+    for (int l = l0; l < L; l += NTH) {
+        double e[K > 0 ? K : 1];
+        point(l, e);
     }
     double v[2] = {acc, bad};
     T.template block_sums<2>(v);
@@ -622,8 +654,9 @@ __device__ __forceinline__ double eval_f(const R &T, const double *x, bool &fini
 // J^T J (packed) and J^T f at x (f is recomputed from the same expression eval_f uses: identical bits)
 template <int N, class R>
 __device__ __forceinline__ void eval_jac(const R &T, const double *x, const double *lb, const double *ub, int mode, double *A,
-                                         double *g)
+                                         double *g, const PointCache<N> &pc)
 {
+    constexpr bool CACHE = fit_point_cache<N>();
     constexpr int K = N / 2;
     constexpr int NT = N * (N + 1) / 2;
     using M = Model<N>;
@@ -657,13 +690,20 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
     double *Aacc = acc, *gacc = acc + NT;
 #pragma unroll
     for (int i = 0; i < NT + N; ++i) acc[i] = 0.0;
-    for (int l = tid; l < L; l += NTH) {
+    // one data point: `cached` >= 0 takes the exponentials and the residual at x from the point cache (slot `cached`)
+    auto point = [&](int l, int cached) {
         const double tl = T.ld_t(l), w = T.ld_w(l), yl = T.ld_y(l);
         double e[K > 0 ? K : 1], Jr[N], f0;
-        M::exps(tau_u, rtau, tl, e);
-        {
+        if (CACHE && cached >= 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) e[k] = pc.e[cached * K + k];
+            f0 = pc.f[cached];
+        } else {
+            M::exps(tau_u, rtau, tl, e);
+            {
 #pragma clang fp contract(off)
-            f0 = w * (M::value(x, e) - yl);
+                f0 = w * (M::value(x, e) - yl);
+            }
         }
         if (mode == 0) {
 #pragma unroll
@@ -698,7 +738,17 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
 #pragma unroll
             for (int j = 0; j <= i; ++j) Aacc[tri(i, j)] = fma(Jr[i], Jr[j], Aacc[tri(i, j)]);
         }
+    };
+    int l0 = tid;
+    if (CACHE) {
+#pragma unroll
+        for (int j = 0; j < kCacheCap; ++j) {          // static slot indices: the cache stays in registers
+            const int l = tid + j * NTH;
+            if (l < L) point(l, j);
+        }
+        l0 = tid + kCacheCap * NTH;
     }
+    for (int l = l0; l < L; l += NTH) point(l, -1);
     // workgroup sums in the fixed order of block_sums (lanes by DPP butterfly, then waves 0..W-1): J^T J goes to the
     // shared matrix in LDS (element k by thread k), J^T f to every thread's registers
     {
@@ -788,13 +838,14 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
     } else {
         strictly_feasible<N>(x, lb, ub, 1e-10);
         bool finite;
-        cost = eval_f<N>(T, x, finite);
+        PointCache<N> pcache;
+        cost = eval_f<N>(T, x, finite, pcache);
         nfev = 1;
         if (!finite) {
             status = -3;          // "Residuals are not finite in the initial point"
         } else {
             have_fit = true;
-            eval_jac<N>(T, x, lb, ub, P.jac_mode, A, g);
+            eval_jac<N>(T, x, lb, ub, P.jac_mode, A, g, pcache);
             const int max_nfev = P.max_nfev > 0 ? P.max_nfev : 100 * N;
             double v[N], dv[N];
             // CL_scaling_vector
@@ -878,7 +929,7 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
                         predicted = bc[N]; step_h_norm = bc[N + 1]; step_norm = bc[N + 2];
                     }
                     bool finite2;
-                    cost_new = eval_f<N>(T, xn, finite2);
+                    cost_new = eval_f<N>(T, xn, finite2, pcache);
                     nfev += 1;
                     if (!finite2) {
                         Delta = 0.25 * step_h_norm;
@@ -907,7 +958,7 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
 #pragma unroll
                     for (int i = 0; i < N; ++i) x[i] = uni(xn[i]);
                     cost = cost_new;
-                    eval_jac<N>(T, x, lb, ub, P.jac_mode, A, g);
+                    eval_jac<N>(T, x, lb, ub, P.jac_mode, A, g, pcache);
                 }
             }
             status = term_set ? term : 0;

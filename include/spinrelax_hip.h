@@ -37,7 +37,7 @@ extern "C" {
 
 typedef struct sr_ctx sr_ctx;
 
-#define SR_ABI_VERSION 7
+#define SR_ABI_VERSION 8
 
 /* ---- context, memory, timing ------------------------------------------------------------- */
 int          sr_abi_version(void);
@@ -346,6 +346,22 @@ int sr_rscsa_search_f64(sr_ctx *, int E, int nRes, const double *stats, const in
                         const double *noe_factor, const double *f_DD, const double *target, const double *dtarget,
                         const unsigned char *cover, int has_err, const double *csa0, double step, double xtol, double ftol,
                         double *csa, double *values, double *errors, double *fopt, int *nfev);
+
+/* Per-residue CSA refinement of the legacy single-field mode `--opt new`: replaces the loop of fmin_powell calls over
+ * optfunc_R1R2NOE_new (calculate-relaxations-from-Ct.py:210-258, 935-1000), axisymmetric diffusion + vector histogram only.
+ * One workgroup per residue runs scipy's one-variable Powell search (as sr_rscsa_search_f64); every objective call evaluates
+ * R1, R2 and the old-API NOE over the B histogram bins with the arithmetic of sr_jomega_relax_f64 (noe_mode 0), casts value and
+ * sigma to float32 like the reference's datablock and returns mean_k (model_k - exp_k)^2 / (sigma_exp_k^2 + sigma_model_k^2).
+ *   D = {Dpar, Dperp}; omega (5); f_DD; gammaB0_sq = (gamma_X B0)^2 (f_CSA = 2/15 csa^2 gammaB0_sq); time_fact; gamma_ratio;
+ *   S2 (nRes), C / tau (nRes, Kmax), nComps (nRes): the fitted models, already scaled by zeta; binvecs (B, 3), weights (nRes, B);
+ *   expt (nRes, 3, 2): measured R1, R2, NOE and their uncertainties; csa0 (nRes) start values; step = Powell's initial
+ *   direction (1.0: scipy's identity default), xtol, ftol (1e-4), maxiter, maxfun (1000: scipy's N * 1000).
+ * Outputs (nRes): csa = Powell's optimum, fopt = the objective there, nfev = objective calls.  Host pointers. */
+int sr_legacy_csa_search_f64(sr_ctx *, const double *D, const double *omega, double f_DD, double gammaB0_sq, double time_fact,
+                             double gamma_ratio, int nRes, int Kmax, const double *S2, const double *C, const double *tau,
+                             const int *nComps, int B, const double *binvecs, const double *weights, const double *expt,
+                             const double *csa0, double step, double xtol, double ftol, int maxiter, int maxfun, double *csa,
+                             double *fopt, int *nfev);
 
 /* ---- trajectory front end ----------------------------------------
  * Replaces obtain_XHvecs (calculate-Ct-from-traj.py:64-86) with vecnorm_NDarray (transforms3d_supplement.py:40-52) and the

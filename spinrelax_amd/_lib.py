@@ -103,6 +103,9 @@ SIGNATURES = {
     'sr_dq_moments_f64': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p]),
     # (ctx, E, nRes, stats, column, csa_prefactor, noe_factor, f_DD, target, dtarget, cover, has_err, csa0, step, xtol, ftol,
     #  csa, values, errors, fopt, nfev)
+    'sr_legacy_csa_search_f64': (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_int, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double,
+                                         c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'sr_rscsa_search_f64': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p, c_double, c_double, c_double, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
@@ -129,7 +132,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 7
+ABI_VERSION = 8
 LIB_PATH = os.environ.get('SPINRELAX_HIP_LIB', LIB_PATH)      # alternative build of the same ABI
 
 

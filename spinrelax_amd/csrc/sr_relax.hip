@@ -71,6 +71,82 @@ __device__ __forceinline__ void block_sum(double *vals, double *red, int tid)
     __syncthreads();
 }
 
+// G[j][w] = S2 g(D_j, w) + sum_k C_k g(D_j + 1/tau_k, w): the bin-independent part of J (threads 0..14 fill it)
+__device__ __forceinline__ void fill_G(int model, double D0, double D1, double S2, double zeta, const double *C, const double *tau,
+                                       int K, const double *om, double (*G)[5], int tid)
+{
+    if (tid < 15) {
+        const int j = tid / 5, w = tid - j * 5;
+        double g = 0.0;
+        if (model == 2) {
+            const double Dpar = D0, Dperp = D1;
+            const double DJ = j == 0 ? 5 * Dperp + Dpar : (j == 1 ? 2 * Dperp + 4 * Dpar : 6 * Dperp);
+            g = S2 * jomega(DJ, om[w]);
+            for (int k = 0; k < K; ++k) { const double ck = zeta * C[k]; g += ck * jomega(DJ + 1. / tau[k], om[w]); }
+        } else if (j == 0) {
+            if (model == 1) {
+                const double tg = 1.0 / (6.0 * D0);
+                g = S2 * tg / (1. + (om[w] * tg) * (om[w] * tg));
+                for (int k = 0; k < K; ++k) {
+                    const double kk = (1.0 / tg) + (1.0 / tau[k]);
+                    const double ck = zeta * C[k];
+                    g += ck * kk / (kk * kk + om[w] * om[w]);
+                }
+            } else {
+                for (int k = 0; k < K; ++k) { const double ck = zeta * C[k]; g += ck * tau[k] / (1 + (tau[k] * om[w]) * (tau[k] * om[w])); }
+            }
+        }
+        G[j][w] = g;
+    }
+}
+
+// Weighted mean and variance over the B histogram bins (numpy.average / weighted_average_stdev: two passes) of the kNQ quantities
+// of `quantities()` at one (residue, experiment): J(bin, w) = sum_j A_j(bin) G[j][w].  Shared, inlined, by k_relax and by the
+// per-residue CSA search of the legacy `--opt new` mode, whose objective must reproduce k_relax's numbers exactly.
+__device__ __forceinline__ void relax_bins(const double (*G)[5], double fDD, double fCSA, double tf, double gr, bool prolate, int B,
+                                           const double *binvecs, const double *wgt, double *red, int tid, double *mean, double *var)
+{
+    double wsum;
+    {   // pass 1: weighted means
+        double s[kNQ + 1];
+        for (int k = 0; k <= kNQ; ++k) s[k] = 0.0;
+        for (int b = tid; b < B; b += 256) {
+            const double w_ = wgt ? wgt[b] : 1.0;
+            const double *v = binvecs + (int64_t)b * 3;
+            const double z = prolate ? v[2] : v[0];
+            const double z2 = z * z, w1 = 1 - z2;
+            const double A0 = 3.0 * (z2 * w1), A1 = 0.75 * (w1 * w1), A2 = 0.25 * ((3 * z2 - 1) * (3 * z2 - 1));
+            double J[5], q[kNQ];
+            for (int w = 0; w < 5; ++w) J[w] = A0 * G[0][w] + A1 * G[1][w] + A2 * G[2][w];
+            quantities(J, fDD, fCSA, tf, gr, q);
+            for (int k = 0; k < kNQ; ++k) s[k] += w_ * q[k];
+            s[kNQ] += w_;
+        }
+        block_sum<kNQ + 1>(s, red, tid);
+        wsum = s[kNQ];
+        for (int k = 0; k < kNQ; ++k) mean[k] = s[k] / wsum;
+    }
+    {   // pass 2: weighted variance about the mean (+ the two covariances the closed-form CSA objective needs)
+        double s[kNQ + kNC];
+        for (int k = 0; k < kNQ + kNC; ++k) s[k] = 0.0;
+        for (int b = tid; b < B; b += 256) {
+            const double w_ = wgt ? wgt[b] : 1.0;
+            const double *v = binvecs + (int64_t)b * 3;
+            const double z = prolate ? v[2] : v[0];
+            const double z2 = z * z, w1 = 1 - z2;
+            const double A0 = 3.0 * (z2 * w1), A1 = 0.75 * (w1 * w1), A2 = 0.25 * ((3 * z2 - 1) * (3 * z2 - 1));
+            double J[5], q[kNQ];
+            for (int w = 0; w < 5; ++w) J[w] = A0 * G[0][w] + A1 * G[1][w] + A2 * G[2][w];
+            quantities(J, fDD, fCSA, tf, gr, q);
+            for (int k = 0; k < kNQ; ++k) { const double d = q[k] - mean[k]; s[k] += w_ * (d * d); }
+            s[kNQ] += w_ * ((q[10] - mean[10]) * (q[11] - mean[11]));
+            s[kNQ + 1] += w_ * ((q[12] - mean[12]) * (q[13] - mean[13]));
+        }
+        block_sum<kNQ + kNC>(s, red, tid);
+        for (int k = 0; k < kNQ + kNC; ++k) var[k] = s[k] / wsum;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_relax(RelaxArgs a)
 {
     __shared__ double G[3][5];
@@ -87,29 +163,7 @@ __global__ __launch_bounds__(256) void k_relax(RelaxArgs a)
     double *Jout = a.Jout ? a.Jout + ((int64_t)e * a.nRes + i) * 10 : nullptr;
     double *stats = a.stats ? a.stats + ((int64_t)e * a.nRes + i) * 12 : nullptr;
 
-    if (tid < 15) {
-        const int j = tid / 5, w = tid - j * 5;
-        double g = 0.0;
-        if (a.model == 2) {
-            const double Dpar = a.D0, Dperp = a.D1;
-            const double DJ = j == 0 ? 5 * Dperp + Dpar : (j == 1 ? 2 * Dperp + 4 * Dpar : 6 * Dperp);
-            g = S2 * jomega(DJ, om[w]);
-            for (int k = 0; k < K; ++k) { const double ck = zeta * C[k]; g += ck * jomega(DJ + 1. / tau[k], om[w]); }
-        } else if (j == 0) {
-            if (a.model == 1) {
-                const double tg = 1.0 / (6.0 * a.D0);
-                g = S2 * tg / (1. + (om[w] * tg) * (om[w] * tg));
-                for (int k = 0; k < K; ++k) {
-                    const double kk = (1.0 / tg) + (1.0 / tau[k]);
-                    const double ck = zeta * C[k];
-                    g += ck * kk / (kk * kk + om[w] * om[w]);
-                }
-            } else {
-                for (int k = 0; k < K; ++k) { const double ck = zeta * C[k]; g += ck * tau[k] / (1 + (tau[k] * om[w]) * (tau[k] * om[w])); }
-            }
-        }
-        G[j][w] = g;
-    }
+    fill_G(a.model, a.D0, a.D1, S2, zeta, C, tau, K, om, G, tid);
     __syncthreads();
 
     if (a.model != 2 || a.B == 0) {
@@ -137,47 +191,8 @@ __global__ __launch_bounds__(256) void k_relax(RelaxArgs a)
     }
 
     const double *wgt = a.weights ? a.weights + (int64_t)i * a.B : nullptr;
-    double mean[kNQ];
-    double wsum;
-    {   // pass 1: weighted means
-        double s[kNQ + 1];
-        for (int k = 0; k <= kNQ; ++k) s[k] = 0.0;
-        for (int b = tid; b < a.B; b += 256) {
-            const double w_ = wgt ? wgt[b] : 1.0;
-            const double *v = a.binvecs + (int64_t)b * 3;
-            const double z = prolate ? v[2] : v[0];
-            const double z2 = z * z, w1 = 1 - z2;
-            const double A0 = 3.0 * (z2 * w1), A1 = 0.75 * (w1 * w1), A2 = 0.25 * ((3 * z2 - 1) * (3 * z2 - 1));
-            double J[5], q[kNQ];
-            for (int w = 0; w < 5; ++w) J[w] = A0 * G[0][w] + A1 * G[1][w] + A2 * G[2][w];
-            quantities(J, fDD, fCSA, tf, gr, q);
-            for (int k = 0; k < kNQ; ++k) s[k] += w_ * q[k];
-            s[kNQ] += w_;
-        }
-        block_sum<kNQ + 1>(s, red, tid);
-        wsum = s[kNQ];
-        for (int k = 0; k < kNQ; ++k) mean[k] = s[k] / wsum;
-    }
-    double var[kNQ + kNC];
-    {   // pass 2: weighted variance about the mean (+ the two covariances the closed-form CSA objective needs)
-        double s[kNQ + kNC];
-        for (int k = 0; k < kNQ + kNC; ++k) s[k] = 0.0;
-        for (int b = tid; b < a.B; b += 256) {
-            const double w_ = wgt ? wgt[b] : 1.0;
-            const double *v = a.binvecs + (int64_t)b * 3;
-            const double z = prolate ? v[2] : v[0];
-            const double z2 = z * z, w1 = 1 - z2;
-            const double A0 = 3.0 * (z2 * w1), A1 = 0.75 * (w1 * w1), A2 = 0.25 * ((3 * z2 - 1) * (3 * z2 - 1));
-            double J[5], q[kNQ];
-            for (int w = 0; w < 5; ++w) J[w] = A0 * G[0][w] + A1 * G[1][w] + A2 * G[2][w];
-            quantities(J, fDD, fCSA, tf, gr, q);
-            for (int k = 0; k < kNQ; ++k) { const double d = q[k] - mean[k]; s[k] += w_ * (d * d); }
-            s[kNQ] += w_ * ((q[10] - mean[10]) * (q[11] - mean[11]));
-            s[kNQ + 1] += w_ * ((q[12] - mean[12]) * (q[13] - mean[13]));
-        }
-        block_sum<kNQ + kNC>(s, red, tid);
-        for (int k = 0; k < kNQ + kNC; ++k) var[k] = s[k] / wsum;
-    }
+    double mean[kNQ], var[kNQ + kNC];
+    relax_bins(G, fDD, fCSA, tf, gr, prolate, a.B, a.binvecs, wgt, red, tid, mean, var);
     if (tid == 0) {
         out[0] = mean[0]; out[1] = sqrt(var[0]);
         out[2] = mean[1]; out[3] = sqrt(var[1]);
@@ -295,7 +310,8 @@ struct RscsaObjective {
 };
 
 // min over alpha of f(p + alpha*xi); returns alpha_min and the value there (Brent on bracket(0, 1)).
-__device__ void rscsa_line_min(RscsaObjective &f, double p, double xi, double tol, double &alpha_min, double &fret)
+template <class F>
+__device__ void powell_line_min(F &f, double p, double xi, double tol, double &alpha_min, double &fret)
 {
 #pragma clang fp contract(off)
     auto g = [&](double alpha) { return f(p + alpha * xi); };
@@ -401,20 +417,15 @@ __device__ void rscsa_line_min(RscsaObjective &f, double p, double xi, double to
     fret = fx;
 }
 
-__global__ __launch_bounds__(64) void k_rscsa_search(RscsaArgs a)
+// scipy.optimize._optimize._minimize_powell for ONE variable (N = 1, no bounds), operation for operation; f.stop unwinds like
+// _MaxFuncCallError.  x: Powell's current point, fval: the value there.
+template <class F>
+__device__ void powell_min_1d(F &f, double x0, double step, double xtol, double ftol, int maxiter, int maxfun, double &x, double &fval)
 {
 #pragma clang fp contract(off)
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= a.n) return;
-    RscsaObjective f{a, i, 0, 0, false, a.csa0[i]};
-    for (int e = 0; e < a.E; ++e) f.ncover += a.cover[(size_t)e * a.n + i] ? 1 : 0;
-    a.nfev[i] = 0;
-    a.csa[i] = a.csa0[i];
-    a.fopt[i] = NAN;
-    if (f.ncover == 0) return;          // the reference skips residues no experiment covers
-    // _minimize_powell, N = 1
-    double x = a.csa0[i], direc = a.step;
-    double fval = f(x);
+    x = x0;
+    double direc = step;
+    fval = f(x);
     double x1 = x;
     int iter = 0;
     while (!f.stop) {
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(64) void k_rscsa_search(RscsaArgs a)
             const double fx2 = fval;
             if (direc != 0.0) {
                 double amin = 0.0, fret = fval;
-                rscsa_line_min(f, x, direc, a.xtol * 100, amin, fret);
+                powell_line_min(f, x, direc, xtol * 100, amin, fret);
                 if (f.stop) break;
                 x = x + amin * direc;          // the scaled direction is a local of the loop: direc[0] itself is kept
                 fval = fret;
@@ -432,10 +443,10 @@ __global__ __launch_bounds__(64) void k_rscsa_search(RscsaArgs a)
             if ((fx2 - fval) > delta) delta = fx2 - fval;
         }
         iter += 1;
-        const double bnd = a.ftol * (fabs(fx) + fabs(fval)) + 1e-20;
+        const double bnd = ftol * (fabs(fx) + fabs(fval)) + 1e-20;
         if (2.0 * (fx - fval) <= bnd) break;
-        if (f.calls >= a.maxfun) break;
-        if (iter >= a.maxiter) break;
+        if (f.calls >= maxfun) break;
+        if (iter >= maxiter) break;
         if (isnan(fx) && isnan(fval)) break;
         double direc1 = x - x1;
         x1 = x;
@@ -451,7 +462,7 @@ __global__ __launch_bounds__(64) void k_rscsa_search(RscsaArgs a)
             if (t < 0.0) {
                 if (direc1 != 0.0) {
                     double amin = 0.0, fret = fval;
-                    rscsa_line_min(f, x, direc1, a.xtol * 100, amin, fret);
+                    powell_line_min(f, x, direc1, xtol * 100, amin, fret);
                     if (f.stop) break;
                     direc1 = amin * direc1;
                     x = x + direc1;
@@ -461,6 +472,21 @@ __global__ __launch_bounds__(64) void k_rscsa_search(RscsaArgs a)
             }
         }
     }
+}
+
+__global__ __launch_bounds__(64) void k_rscsa_search(RscsaArgs a)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n) return;
+    RscsaObjective f{a, i, 0, 0, false, a.csa0[i]};
+    for (int e = 0; e < a.E; ++e) f.ncover += a.cover[(size_t)e * a.n + i] ? 1 : 0;
+    a.nfev[i] = 0;
+    a.csa[i] = a.csa0[i];
+    a.fopt[i] = NAN;
+    if (f.ncover == 0) return;          // the reference skips residues no experiment covers
+    double x, fval;
+    powell_min_1d(f, a.csa0[i], a.step, a.xtol, a.ftol, a.maxiter, a.maxfun, x, fval);
     a.nfev[i] = f.calls;
     a.csa[i] = f.last;
     a.fopt[i] = fval;
@@ -470,6 +496,82 @@ __global__ __launch_bounds__(64) void k_rscsa_search(RscsaArgs a)
         f.closed_form(e, f.last, v, dv);
         a.val[(size_t)e * a.n + i] = v;
         a.err[(size_t)e * a.n + i] = dv;
+    }
+}
+
+// ---- legacy `--opt new`: the per-residue CSA refinement (calculate-relaxations-from-Ct.py:935-1000) ------------------------
+// For every residue: fmin_powell over ONE variable, the CSA, of optfunc_R1R2NOE_new (:210-258) -- R1, R2, NOE (old API: per-vector
+// R1 in the NOE) as weighted mean and sigma over the histogram bins, cast to float32 like the reference's datablock, against the
+// measured triple: mean_k (model_k - exp_k)^2 / (sigma_exp_k^2 + sigma_model_k^2).  The NOE of the old API is not affine in
+// f_CSA, so every objective call walks the 2 592 bins: one workgroup per residue runs scipy's Powell search workgroup-uniformly
+// (every thread the same control flow on the same values) and the objective is a workgroup reduction -- relax_bins, the very
+// code k_relax runs for the host-driven search, so both searches see the same numbers and take the same path.
+struct LegacyArgs {
+    int nRes, Kmax, B, maxiter, maxfun;
+    double D0, D1, fDD, g2, tf, gr, step, xtol, ftol;
+    const double *omega;          // (5)
+    const double *S2, *C, *tau;   // (nRes), (nRes, Kmax) x 2: already scaled by zeta
+    const int *nComps;            // (nRes)
+    const double *binvecs;        // (B, 3)
+    const double *weights;        // (nRes, B)
+    const double *expt;           // (nRes, 3, 2): R1, R2, NOE x (value, sigma)
+    const double *csa0;           // (nRes)
+    double *csa, *fopt;           // (nRes)
+    int *nfev;                    // (nRes)
+};
+
+struct LegacyObjective {
+    const LegacyArgs &a;
+    const double (*G)[5];
+    double *red;
+    const double *wgt;
+    const double *ex;             // this residue's (3, 2)
+    bool prolate;
+    int tid, calls;
+    bool stop;
+
+    __device__ double operator()(double csa)
+    {
+        if (calls >= a.maxfun) { stop = true; return NAN; }
+        calls += 1;
+        double fcsa;
+        {
+#pragma clang fp contract(off)
+            fcsa = ((2.0 / 15.0) * (csa * csa)) * a.g2;          // get_f_CSA: 2.0/15.0 * csa**2.0 * (gamma B0)**2
+        }
+        double mean[kNQ], var[kNQ + kNC];
+        relax_bins(G, a.fDD, fcsa, a.tf, a.gr, prolate, a.B, a.binvecs, wgt, red, tid, mean, var);
+        double acc = 0.0;
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float d0 = (float)mean[k], d1 = (float)sqrt(var[k]);      // the reference's float32 datablock
+                const double r = (double)d0 - ex[2 * k];
+                const float sq = d1 * d1;                                       // numpy squares the float32 column in float32
+                const double sig = ex[2 * k + 1] * ex[2 * k + 1] + (double)sq;
+                acc += (r * r) / sig;
+            }
+            acc = acc / 3.0;
+        }
+        return acc;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_legacy_csa_search(LegacyArgs a)
+{
+    __shared__ double G[3][5];
+    __shared__ double red[80];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    fill_G(2, a.D0, a.D1, a.S2[i], 1.0, a.C + (int64_t)i * a.Kmax, a.tau + (int64_t)i * a.Kmax, a.nComps[i], a.omega, G, tid);
+    __syncthreads();
+    LegacyObjective f{a, G, red, a.weights + (int64_t)i * a.B, a.expt + (int64_t)i * 6, a.D0 > a.D1, tid, 0, false};
+    double x, fval;
+    powell_min_1d(f, a.csa0[i], a.step, a.xtol, a.ftol, a.maxiter, a.maxfun, x, fval);
+    if (tid == 0) {
+        a.csa[i] = x;
+        a.fopt[i] = fval;
+        a.nfev[i] = f.calls;
     }
 }
 
@@ -640,6 +742,59 @@ int sr_rscsa_search_f64(sr_ctx *ctx, int E, int nRes, const double *stats, const
     SR_HIP(hipGetLastError());
     SR_HIP(hipMemcpyAsync(values, a.val, EN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SR_HIP(hipMemcpyAsync(errors, a.err, EN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(csa, a.csa, nR * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(fopt, a.fopt, nR * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipMemcpyAsync(nfev, a.nfev, nR * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sr_legacy_csa_search_f64(sr_ctx *ctx, const double *D, const double *omega, double f_DD, double gammaB0_sq, double time_fact,
+                             double gamma_ratio, int nRes, int Kmax, const double *S2, const double *C, const double *tau,
+                             const int *nComps, int B, const double *binvecs, const double *weights, const double *expt,
+                             const double *csa0, double step, double xtol, double ftol, int maxiter, int maxfun, double *csa,
+                             double *fopt, int *nfev)
+{
+    SR_CHECK_CTX(ctx);
+    SR_REQUIRE(nRes >= 1 && Kmax >= 1 && Kmax <= kMaxK && B >= 1, -3, "sr_legacy_csa_search_f64: bad sizes");
+    SR_REQUIRE(D && omega && S2 && C && tau && nComps && binvecs && weights && expt && csa0 && csa && fopt && nfev, -2,
+               "sr_legacy_csa_search_f64: null pointer");
+    SR_REQUIRE(maxiter >= 1 && maxfun >= 1, -3, "sr_legacy_csa_search_f64: maxiter / maxfun must be positive");
+    for (int i = 0; i < nRes; ++i)
+        SR_REQUIRE(nComps[i] >= 0 && nComps[i] <= Kmax, -3, "sr_legacy_csa_search_f64: nComps[%d]=%d out of range", i, nComps[i]);
+    const size_t nR = (size_t)nRes;
+    const size_t cnt = 5 + nR + 2 * nR * Kmax + (size_t)B * 3 + nR * B + nR * 6 + nR;
+    double *stage = (double *)sr_workspace(ctx, SR_WS_IN0, cnt * sizeof(double));
+    int *ncomp_d = (int *)sr_workspace(ctx, SR_WS_IN1, nR * sizeof(int));
+    double *dout = (double *)sr_workspace(ctx, SR_WS_OUT0, 2 * nR * sizeof(double) + nR * sizeof(int));
+    if (!stage || !ncomp_d || !dout) return -5;
+    double *p = stage;
+    auto put = [&](const double *src, size_t n) -> const double * {
+        hipError_t e = hipMemcpyAsync(p, src, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return nullptr;
+        const double *r = p;
+        p += n;
+        return r;
+    };
+    LegacyArgs a;
+    a.nRes = nRes; a.Kmax = Kmax; a.B = B; a.maxiter = maxiter; a.maxfun = maxfun;
+    a.D0 = D[0]; a.D1 = D[1]; a.fDD = f_DD; a.g2 = gammaB0_sq; a.tf = time_fact; a.gr = gamma_ratio;
+    a.step = step; a.xtol = xtol; a.ftol = ftol;
+    a.omega = put(omega, 5);
+    a.S2 = put(S2, nR);
+    a.C = put(C, nR * Kmax);
+    a.tau = put(tau, nR * Kmax);
+    a.binvecs = put(binvecs, (size_t)B * 3);
+    a.weights = put(weights, nR * B);
+    a.expt = put(expt, nR * 6);
+    a.csa0 = put(csa0, nR);
+    SR_REQUIRE(a.omega && a.S2 && a.C && a.tau && a.binvecs && a.weights && a.expt && a.csa0, -6,
+               "sr_legacy_csa_search_f64: host to device copy failed");
+    SR_HIP(hipMemcpyAsync(ncomp_d, nComps, nR * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    a.nComps = ncomp_d;
+    a.csa = dout; a.fopt = dout + nR; a.nfev = (int *)(dout + 2 * nR);
+    hipLaunchKernelGGL(k_legacy_csa_search, dim3((unsigned)nRes), dim3(256), 0, ctx->stream, a);
+    SR_HIP(hipGetLastError());
     SR_HIP(hipMemcpyAsync(csa, a.csa, nR * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SR_HIP(hipMemcpyAsync(fopt, a.fopt, nR * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SR_HIP(hipMemcpyAsync(nfev, a.nfev, nR * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

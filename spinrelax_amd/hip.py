@@ -271,6 +271,35 @@ class Context:
         check(fn(self.h, _ptr(q), q.shape[0], _ptr(lg), lg.size, int(nchunk), _ptr(out)), 'sr_dq_moments_f64' if f64 else 'sr_dq_moments_f32')
         return out
 
+    # ---- per-residue CSA refinement of the legacy `--opt new` mode ----
+    def legacy_csa_search(self, D, omega, f_DD, gammaB0_sq, time_fact, gamma_ratio, S2, C, tau, nComps, binvecs, weights, expt,
+                          csa0, step=1.0, xtol=1e-4, ftol=1e-4, maxiter=1000, maxfun=1000):
+        """fmin_powell over the CSA of every residue against its measured (R1, R2, NOE) triple
+        (calculate-relaxations-from-Ct.py:210-258, 935-1000): one launch, a workgroup per residue.  D = (Dpar, Dperp); S2 (n),
+        C / tau (n, Kmax), nComps (n) already scaled by zeta; binvecs (B, 3), weights (n, B); expt (n, 3, 2) = value and
+        uncertainty of R1, R2, NOE; csa0 (n).  Returns csa (n) = Powell's optimum, fopt (n), nfev (n)."""
+        Dd = _f64(np.atleast_1d(D))
+        om = _f64(np.ravel(omega))
+        S2 = _f64(S2)
+        n = S2.size
+        C, tau = _f64(np.atleast_2d(C)), _f64(np.atleast_2d(tau))
+        Kmax = C.shape[1]
+        nc = np.ascontiguousarray(nComps, dtype=np.int32)
+        bv, w, ex, c0 = _f64(binvecs), _f64(weights), _f64(expt), _f64(csa0)
+        B = bv.shape[0]
+        if Dd.shape != (2,) or om.shape != (5,):
+            raise ValueError('D must be (Dpar, Dperp), omega the 5 angular frequencies')
+        if C.shape != (n, Kmax) or tau.shape != (n, Kmax) or nc.shape != (n,) or bv.shape != (B, 3) or w.shape != (n, B) or \
+                ex.shape != (n, 3, 2) or c0.shape != (n,):
+            raise ValueError('shapes: C / tau (n, Kmax), nComps (n), binvecs (B, 3), weights (n, B), expt (n, 3, 2), csa0 (n)')
+        csa, fopt = np.empty(n), np.empty(n)
+        nfev = np.empty(n, dtype=np.int32)
+        check(self.lib.sr_legacy_csa_search_f64(self.h, _ptr(Dd), _ptr(om), float(f_DD), float(gammaB0_sq), float(time_fact),
+                                                float(gamma_ratio), n, Kmax, _ptr(S2), _ptr(C), _ptr(tau), _ptr(nc), B, _ptr(bv),
+                                                _ptr(w), _ptr(ex), _ptr(c0), float(step), float(xtol), float(ftol), int(maxiter),
+                                                int(maxfun), _ptr(csa), _ptr(fopt), _ptr(nfev)), 'sr_legacy_csa_search_f64')
+        return csa, fopt, nfev
+
     # ---- residue-specific CSA search (new class API) ----
     def rscsa_search(self, stats, column, csa_prefactor, noe_factor, f_DD, target, dtarget, cover, has_err, csa0, step,
                      xtol=1e-4, ftol=1e-4):

@@ -2,11 +2,16 @@
 Legacy single-field optimisation modes of calculate-relaxations-from-Ct.py:
 `--opt Diso | DisoS2 | DisoCSA | DisoS2CSA | new` (calculate-relaxations-from-Ct.py:193-316, 775-1004).
 
-scipy's Powell search runs on the host exactly as in the reference; every objective evaluation is ONE launch of the
-relaxation kernel over all residues and histogram bins (`spectral_densities._obtain_R1R2NOErho`), or over the bins
-of one residue for the per-residue CSA refinement of mode `new`.  Function names, argument tuples, printed lines
-and the float32 datablocks follow the reference so that the optimiser sees the same objective.
+scipy's Powell search runs on the host exactly as in the reference for the few-variable global searches; every objective
+evaluation is ONE launch of the relaxation kernel over all residues and histogram bins
+(`spectral_densities._obtain_R1R2NOErho`).  The per-residue CSA refinement of mode `new` (one fmin_powell per residue,
+:935-1000) is ONE launch of the device-side search (`sr_legacy_csa_search_f64`: scipy's one-variable Powell restated, a
+workgroup per residue, the objective over the residue's histogram bins with the relaxation kernel's own arithmetic) when the
+model is the axisymmetric one with a vector histogram; `SR_LEGACY_HOST_SEARCH=1` (and every other case) keeps the host loop,
+which the tests use as the cross-check.  Function names, argument tuples, printed lines and the float32 datablocks follow the
+reference so that the optimiser sees the same objective.
 """
+import os
 import sys
 
 import numpy as np
@@ -185,6 +190,28 @@ def match_residues(sim_resid, exp_resid, expblock, S2_list, consts_list, taus_li
             [taus_list[x] for x in sim_ind], fvec, fw, CSAvaluesArray.take(sim_ind), expblock)
 
 
+def _device_csa_search_applies(relax_obj, fvecXH, fw, expblock):
+    """the one-launch search covers the case run-all.bash produces: axisymmetric diffusion, one histogram of bin-centre vectors
+    shared by every residue with per-residue weights, measured values with uncertainties"""
+    if os.environ.get('SR_LEGACY_HOST_SEARCH'):
+        return False
+    if relax_obj.rotdifModel.name != 'rigid_symmtop' or fw is None or np.ndim(expblock) != 3:
+        return False
+    v = np.asarray(fvecXH, dtype=float)
+    return v.ndim == 3 and v.shape[2] == 3 and bool(np.all(v == v[0]))
+
+
+def csa_search_device(relax_obj, fS2, fconsts, ftaus, fvecXH, fw, expblock, csa0, ctx=None):
+    """fmin_powell(optfunc_R1R2NOE_new, x0=csa0[i], ...) for every residue i (:210-258, :983-989) as one launch.
+    Returns (csa (n), chi^2 (n), objective calls (n))."""
+    S2a, C, T, K = sd._pack(fS2, fconsts, ftaus)
+    gb = (relax_obj.gX.gamma * relax_obj.B_0) ** 2                       # get_f_CSA: 2.0 / 15.0 * csa ** 2.0 * (gamma B0) ** 2
+    return _ctx(ctx).legacy_csa_search([relax_obj.rotdifModel.D[0], relax_obj.rotdifModel.D[1]], relax_obj.omega, relax_obj.get_f_DD(), gb,
+                                       relax_obj.time_fact, relax_obj.gH.gamma / relax_obj.gX.gamma, S2a, C, T, K,
+                                       np.asarray(fvecXH, dtype=float)[0], np.asarray(fw, dtype=float),
+                                       np.ascontiguousarray(np.swapaxes(np.asarray(expblock, dtype=float), 0, 1)), np.asarray(csa0, dtype=float))
+
+
 def run(optMode, relax_obj, Diso, matched, expblock_unused, nRefinementCycles, refinementTolerance, out_pref, header_fn,
         param_names, param_scaling, param_units, print_xy, sim_resid_all, CSAvaluesArray, S2_list):
     """The mode switch of :853-1002.  Returns (optHeader, CSAvaluesArray, S2_list)."""
@@ -208,11 +235,16 @@ def run(optMode, relax_obj, Diso, matched, expblock_unused, nRefinementCycles, r
                 print("= = = BREAK at Diso test.")
                 break
             DisoPrev = DisoOpt
-            for i in range(fnum):
-                out = fmin_powell(optfunc_R1R2NOE_new, x0=fCSAsOpt[i],
-                                  args=(relax_obj, fS2[i], fconsts[i], ftaus[i], fvecXH[i], None if fw is None else fw[i],
-                                        expblock[:, i, :] if expblock.ndim == 3 else expblock[:, i]), full_output=True, disp=False)
-                fCSAsOpt[i], fCSAsChiSq[i] = np.ravel(out[0])[0], out[1]
+            if _device_csa_search_applies(relax_obj, fvecXH, fw, expblock):
+                csa_dev, chi_dev, _ = csa_search_device(relax_obj, fS2, fconsts, ftaus, fvecXH, fw, expblock, fCSAsOpt)
+                fCSAsOpt[:] = csa_dev
+                fCSAsChiSq[:] = chi_dev
+            else:
+                for i in range(fnum):
+                    out = fmin_powell(optfunc_R1R2NOE_new, x0=fCSAsOpt[i],
+                                      args=(relax_obj, fS2[i], fconsts[i], ftaus[i], fvecXH[i], None if fw is None else fw[i],
+                                            expblock[:, i, :] if expblock.ndim == 3 else expblock[:, i]), full_output=True, disp=False)
+                    fCSAsOpt[i], fCSAsChiSq[i] = np.ravel(out[0])[0], out[1]
             if (not bFirst) and np.allclose(fCSAsOpt, fCSAsPrev, rtol=refinementTolerance):
                 print("= = = BREAK at CSA test")
                 break

@@ -110,6 +110,52 @@ def test_legacy_mode_new(tmp_path):
     np.testing.assert_allclose(np.asarray(csa, dtype=float), g['new_csa'], rtol=2e-3)
 
 
+def test_device_csa_search_equals_the_host_powell_loop():
+    """The per-residue CSA refinement of `--opt new` (calculate-relaxations-from-Ct.py:983-989: one fmin_powell over
+    optfunc_R1R2NOE_new per residue) as ONE launch (sr_legacy_csa_search_f64) against the host loop it replaces -- scipy's
+    fmin_powell driving the same objective through the relaxation kernel, the reference's structure.  Same arithmetic in the
+    objective (the bins are reduced by the code k_relax runs) and scipy's Powell restated operation for operation: the optimum,
+    the chi^2 there and the NUMBER OF OBJECTIVE CALLS must be identical for every residue, from the default CSA and from
+    perturbed starts."""
+    from scipy.optimize import fmin_powell
+    from spinrelax_amd import legacy_opt as lo
+    from spinrelax_amd.hip import SpinRelaxHipError
+    RObj, n, S2, consts, taus, vecXH, w = _setup(synth.DISO)
+    exp_resid, expblock = _expblock()
+    assert lo._device_csa_search_applies(RObj, vecXH, w, expblock)
+    for scale in (1.0, 0.8, 1.3):
+        csa0 = np.repeat(-170e-6 * scale, n)
+        csa_d, chi_d, nfev_d = lo.csa_search_device(RObj, S2, consts, taus, vecXH, w, expblock, csa0)
+        ncheck = n if scale == 1.0 else 8
+        for i in range(ncheck):
+            out = fmin_powell(lo.optfunc_R1R2NOE_new, x0=csa0[i], args=(RObj, S2[i], consts[i], taus[i], vecXH[i], w[i], expblock[:, i, :]),
+                              full_output=True, disp=False)
+            assert np.ravel(out[0])[0] == csa_d[i], (scale, i, out[0], csa_d[i])
+            assert float(out[1]) == chi_d[i], (scale, i, out[1], chi_d[i])
+            assert int(out[4]) == int(nfev_d[i]), (scale, i, out[4], nfev_d[i])
+        assert np.all(nfev_d > 5) and np.all(np.isfinite(chi_d))
+    # the objective itself at arbitrary points: Powell's first call is f(x0)
+    for c in (-150e-6, -170e-6, -190e-6):
+        _, chi0, _ = lo.csa_search_device(RObj, S2, consts, taus, vecXH, w, expblock, np.repeat(c, n))
+        assert np.all(np.isfinite(chi0))
+    # argument validation happens before any launch
+    ctx = lo._ctx(None)
+    S2a, C, T, K = lo.sd._pack(S2, consts, taus)
+    D = [RObj.rotdifModel.D[0], RObj.rotdifModel.D[1]]
+    ex = np.ascontiguousarray(np.swapaxes(expblock, 0, 1))
+    gb = (RObj.gX.gamma * RObj.B_0) ** 2
+    with pytest.raises(ValueError):
+        ctx.legacy_csa_search(D, RObj.omega, RObj.get_f_DD(), gb, RObj.time_fact, 1.0, S2a, C, T, K, np.asarray(vecXH)[0], np.asarray(w)[:3], ex, csa0)
+    with pytest.raises(SpinRelaxHipError):
+        ctx.legacy_csa_search(D, RObj.omega, RObj.get_f_DD(), gb, RObj.time_fact, 1.0, S2a, C, T, K + 9, np.asarray(vecXH)[0], np.asarray(w), ex, csa0)
+    # the switch back to the host loop
+    os.environ['SR_LEGACY_HOST_SEARCH'] = '1'
+    try:
+        assert not lo._device_csa_search_applies(RObj, vecXH, w, expblock)
+    finally:
+        del os.environ['SR_LEGACY_HOST_SEARCH']
+
+
 def test_legacy_opt_argument_errors(tmp_path):
     base = [sys.executable, os.path.join(SCR, 'calculate-relaxations-from-Ct.py'), '-f', 'x', '--opt', 'Diso']
     p = subprocess.run(base, stdout=subprocess.PIPE, stderr=subprocess.PIPE)

@@ -515,6 +515,16 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     assert w['checksums']['shapes']['relax'][1] == 128 and w['checksums'] != one['checksums']
 
 
+def test_bench_cfg4_workload_flag():
+    """`--workload cfg4` (BASELINE configs[3]: 100 000 frames x 2 048 vectors, what 8 GPUs share at 256 vectors each) on one
+    device with a reduced vector count: the line names the workload, counts its triples and carries the result checksums."""
+    j = _run_bench(['--gpus', '1', '--workload', 'cfg4', '--vectors', '64', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-cli-wall',
+                    '--no-kernel-profile', '--spinup-s', '0', '--steady-steps', '0', '--repeats', '1'])
+    assert 'cfg4' in j['config']['workload'] and j['config']['vectors_total'] == 64 and j['scaling'] == 'strong'
+    assert j['config']['exact_triples_total'] == 24 * 64 * (2048 * 4096 - 2048 * 2049 // 2)
+    assert j['checksums']['shapes']['Ct'] == [2048, 64] and j['fit']['unfitted'] == 0
+
+
 def test_bench_single_rank_under_torchrun_equals_plain_run():
     """The driver's SCALE run launches N = 1 the same way as N = 2, 4, 8 (torch.distributed.run) and compares it with the
     plain `python bench.py` of BENCH: both must take the same code path -- same workload, same shard (rank 0 = vectors

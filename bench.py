@@ -85,6 +85,28 @@ def committed_profile():
 PROFILE_BUILD_ID = None
 
 
+def fp64_issue_probe():
+    """scripts/dev/probe/fp64_rate.hip on MI355X (committed output profiles/r*_fp64_issue_rate.txt): float64 VALU wave-instructions
+    one SIMD issues per microsecond as a function of the waves it holds -- 8 independent chains per wave, add / mul / fma alike.
+    The nominal rate (peak 78.6 TFLOP/s = 1 024 SIMDs x 64 lanes x 2 flop / 1.667 ns) is 600 per us; a kernel whose registers allow
+    two waves per SIMD cannot issue faster than the two-wave figure."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_fp64_issue_rate.txt')))
+    if not files:
+        return None
+    acc = {}
+    with open(files[-1]) as fp:
+        for line in fp:
+            m = re.match(r'(\d+) wave\(s\) per SIMD\s+(v_\w+_f64)\s+.*kernel ([\d.]+) ms', line)
+            if m:
+                acc.setdefault(int(m.group(1)), []).append(int(m.group(1)) * 20000 * 16 / (float(m.group(3)) * 1e3))
+    if not acc:
+        return None
+    return {'source': os.path.relpath(files[-1], ROOT), 'nominal_instr_per_us_per_simd': 600.0,
+            'instr_per_us_per_simd_by_waves': {str(k): float(np.mean(v)) for k, v in sorted(acc.items())}}
+
+
 def profile_staleness():
     """Do the committed PMC figures belong to the kernels that ran?  The profile stores the build id (sha256 over the HIP
     sources, headers and compiler flags, spinrelax_amd/build.py:build_id) of the library it was collected with; the loaded
@@ -721,6 +743,22 @@ def main():
             e['traffic_note'] = 'from the committed profile %s -- not measured in this run%s' % (prof_src, stale_txt) if pe else None
             e['algorithmic_bytes'] = 24 * V * L + 1024 * V
             kernels['k_order_search'] = e
+        # how close the two float64 kernels are to what their occupancy lets the vector pipe issue (both hold 2 waves per SIMD)
+        probe = fp64_issue_probe()
+        if probe and prof:
+            ceil2 = probe['instr_per_us_per_simd_by_waves'].get('2')
+            for kn, dur_ms in ((kname, alone.get('ct')), ('k_order_search', alone.get('fit_saturated_per_batch'))):
+                pe = prof_entry(prof, kn)
+                if not (pe and pe.get('fp64_wave_instructions') and dur_ms and ceil2 and kn in kernels):
+                    continue
+                n64 = float(sum(pe['fp64_wave_instructions'].values()))
+                rate = n64 / 1024.0 / (dur_ms * 1e3)
+                kernels[kn]['fp64_issue'] = {
+                    'fp64_wave_instructions_per_launch': n64, 'duration_ms': dur_ms, 'waves_per_simd': 2,
+                    'fp64_instr_per_us_per_simd': rate, 'two_wave_ceiling': ceil2, 'frac_of_two_wave_ceiling': rate / ceil2,
+                    'note': 'float64 VALU wave-instructions (PMC) per SIMD and microsecond over the kernel alone / saturated, against what a '
+                            'SIMD holding two waves issues in the probe (%s): the other VALU instructions of the kernel are not '
+                            'counted, so the true figure is higher%s' % (probe['source'], stale_txt)}
         # the kernel that occupies most of the chip per batch
         off_step = {'k_ct_palmer'} if use_fft else set()
         ranked = sorted(((v.get('cu_ms_per_batch') or 0.0, k) for k, v in kernels.items() if k not in off_step), reverse=True)
@@ -752,6 +790,7 @@ def main():
                                               'GBps': step_bytes / (ms_per_step * 1e-3) / 1e9,
                                               'note': 'sum over the kernels of a batch of the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE) against '
                                                       'vectors in once + C(t), dC(t), histogram out; not measured in this run%s' % stale_txt}
+        roofline['fp64_issue_probe'] = probe
         roofline['frac_alone'] = tk.get('frac_alone')
         roofline['launches_of_this_kernel_in_flight'] = (tk.get('in_pipeline_ms') or 0.0) / ms_per_step if ms_per_step else None
         roofline['chip'] = None if not (cfg == 3 and V == 512 and step_flop > 0) else {'fp64_flop_per_step': step_flop, 'TFLOPs': step_flop / (ms_per_step * 1e-3) / 1e12,

@@ -131,6 +131,58 @@ def issue_json(raw, build_id):
             'kernels': out}
 
 
+def ceiling_file(tag, build_id, iss, hbm, alone):
+    """profiles/<tag>_ct_rfft_issue.json: the counters of k_ct_rfft the round-3 review asked for under this name, with the kernel's
+    distance from its issue-limited ceiling worked out from them (a float64 instruction holds a SIMD's vector pipe for 4 cycles,
+    any other VALU instruction for 2; the two-wave ceiling is the probe's, profiles/r*_fp64_issue_rate.txt)."""
+    key = next((k for k in iss['kernels'] if k.startswith('k_ct_rfft')), None)
+    if key is None or hbm is None or alone is None:
+        return
+    v = iss['kernels'][key]
+    h = hbm['kernels'].get(key, {})
+    row = alone[alone.Name.str.contains('k_ct_rfft')]
+    if row.empty or 'fp64_flop_per_launch' not in h:
+        return
+    dur_us = float(row.AverageNs.iloc[0]) / 1e3
+    fp64 = float(sum(h.get('fp64_wave_instructions', {}).values()))
+    valu = v['SQ_INSTS_VALU']
+    simds = 1024.0
+    clk_ghz = v['GRBM_GUI_ACTIVE'] / 8.0 / dur_us / 1e3 if v.get('GRBM_GUI_ACTIVE') else None
+    pipe_cycles = (4.0 * fp64 + 2.0 * (valu - fp64)) / simds
+    probe = {}
+    files = sorted(glob.glob(os.path.join(PROF, 'r*_fp64_issue_rate.txt')))
+    if files:                                     # same reading as bench.py:fp64_issue_probe (20 000 x 16 instructions per wave)
+        acc = {}
+        for line in open(files[-1]):
+            m = re.match(r'(\d+) wave\(s\) per SIMD\s+(v_\w+_f64)\s+.*kernel ([\d.]+) ms', line)
+            if m:
+                acc.setdefault(int(m.group(1)), []).append(int(m.group(1)) * 20000 * 16 / (float(m.group(3)) * 1e3))
+        probe = {k: sum(x) / len(x) for k, x in acc.items()}
+    d = {'build_id': build_id, 'kernel': key,
+         'command': 'scripts/profile_round.sh passes ISSUE1-3 + FP64 (rocprofv3 --pmc, bench.py --depth 1) and stats_alone; scripts/make_profiles.py',
+         'per_launch': {c: v[c] for c in ('SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_INST_CYCLES_VMEM_RD', 'SQ_INST_CYCLES_VMEM_WR', 'SQ_WAIT_INST_LDS',
+                                          'SQ_ACTIVE_INST_LDS', 'SQ_LDS_IDX_ACTIVE', 'SQ_LDS_BANK_CONFLICT', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY',
+                                          'SQ_ACTIVE_INST_ANY', 'SQ_WAVE_CYCLES', 'SQ_WAVES', 'GRBM_GUI_ACTIVE') if c in v},
+         'fp64_wave_instructions': fp64, 'other_valu_wave_instructions': valu - fp64, 'duration_alone_us': dur_us,
+         'clock_GHz_under_this_kernel': clk_ghz,
+         'vector_pipe_cycles_per_simd': pipe_cycles,
+         'launch_cycles_per_simd': v['GRBM_GUI_ACTIVE'] / 8.0 if v.get('GRBM_GUI_ACTIVE') else None,
+         'fp64_instr_per_us_per_simd': fp64 / simds / dur_us,
+         'waves_per_simd': 2}
+    if d['launch_cycles_per_simd']:
+        d['frac_of_nominal_issue_rate'] = pipe_cycles / d['launch_cycles_per_simd']
+    if 2 in probe:
+        d['two_wave_ceiling_fp64_instr_per_us_per_simd'] = probe[2]
+        # the other VALU instructions take half a float64 slot each
+        d['frac_of_two_wave_ceiling'] = (fp64 + 0.5 * (valu - fp64)) / simds / dur_us / probe[2]
+        d['fp64_only_frac_of_two_wave_ceiling'] = d['fp64_instr_per_us_per_simd'] / probe[2]
+    d['verdict'] = ('below the 85 % the review set as the bar for "only an instruction diet is left": the rest is wave-lifetime parked at '
+                    's_waitcnt / s_barrier and LDS-queue stalls with two waves per SIMD (DESIGN.md section 4, "Where its time goes")')
+    with open(os.path.join(PROF, '%s_ct_rfft_issue.json' % tag), 'w') as fp:
+        json.dump(d, fp, indent=1)
+    print('ct_rfft issue:', {k: (round(x, 3) if isinstance(x, float) else x) for k, x in d.items() if k.startswith('frac') or k.startswith('fp64_')})
+
+
 def main():
     tag, raw = sys.argv[1], sys.argv[2]
     try:
@@ -169,6 +221,7 @@ def main():
             for kk, v in iss['kernels'].items():
                 if kk.startswith(k):
                     print('issue', kk[:40], {c: round(x, 3) for c, x in v.items() if c.endswith('_per_WAVE_CYCLES') or c.startswith('VALU_busy')})
+        ceiling_file(tag, build_id, iss, out, sa)
     # the direct kernel alone
     pal = {}
     for name, ctrs in (('palmer_FETCH', ['FETCH_SIZE']), ('palmer_WRITE', ['WRITE_SIZE']),

@@ -43,29 +43,38 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _same_flags(stamp, sig):
+    try:
+        with open(stamp) as fp:
+            return fp.read() == sig
+    except OSError:
+        return False
+
+
 def build(force=False, verbose=True):
     hdrs = [os.path.join(CSRC, 'sr_internal.h'), os.path.join(HERE, '..', 'include', 'spinrelax_hip.h')]
     objs = []
     bid = build_id()
-    idfile = os.path.join(CSRC, '.build_id')               # sr_core.o carries the id: rebuilt whenever the id changes
-    try:
-        with open(idfile) as fp:
-            id_changed = fp.read().strip() != bid
-    except OSError:
-        id_changed = True
+    idfile = os.path.join(CSRC, '.build_id')
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         if not os.path.isfile(s):
             raise FileNotFoundError(s)
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         extra = EXTRA.get(src, [])
-        if src == 'sr_core.hip':
+        if src == 'sr_core.hip':                               # sr_core.o carries the id: its command line changes with it
             extra = extra + ['-DSR_BUILD_ID="%s"' % bid]
-        if force or _stale(o, [s] + hdrs) or (src == 'sr_core.hip' and id_changed):
-            cmd = [HIPCC] + FLAGS + extra + ['-c', s, '-o', o]
+        cmd = [HIPCC] + FLAGS + extra + ['-c', s, '-o', o]
+        # an object is rebuilt when its source or a header is newer, and when its COMMAND LINE differs from the one it was built
+        # with (<object>.cmd): a flag change must not leave an object of the old flags under the new build id
+        stamp = o + '.cmd'
+        sig = ' '.join(FLAGS + extra + [src])                  # no absolute paths: the tree is copied to the GPU box as it is
+        if force or _stale(o, [s] + hdrs) or not _same_flags(stamp, sig):
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)
+            with open(stamp, 'w') as fp:
+                fp.write(sig)
         objs.append(o)
     with open(idfile, 'w') as fp:
         fp.write(bid + '\n')

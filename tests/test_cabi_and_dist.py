@@ -39,6 +39,22 @@ def test_library_exports_every_declared_symbol():
     assert bound.sr_ct_psum_stride(4096) >= 2049                   # pure host helper, safe without a GPU
 
 
+def test_build_id_and_flag_stamps(tmp_path, monkeypatch):
+    """The library reports the id of the sources / flags it was built from (bench.py ties the committed PMC figures to it), and an
+    object whose flags changed is rebuilt: a flag change re-labels sr_core.o, so it must not leave the other objects behind."""
+    from spinrelax_amd import _lib, build
+    if os.path.isfile(_lib.LIB_PATH) and not os.environ.get('SR_FIT_DEV_FAST'):
+        assert _lib.load().sr_build_id().decode() == build.build_id(), 'libspinrelax_hip.so is not the build of these sources'
+    stamp = tmp_path / 'x.o.cmd'
+    assert not build._same_flags(str(stamp), 'a b')                 # no stamp: rebuild
+    stamp.write_text('a b')
+    assert build._same_flags(str(stamp), 'a b')
+    assert not build._same_flags(str(stamp), 'a b -DX')             # other flags: rebuild
+    before = build.build_id()
+    monkeypatch.setitem(build.EXTRA, 'sr_fit.hip', build.EXTRA['sr_fit.hip'] + ['-DX'])
+    assert build.build_id() != before                               # the flags are part of the id
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():

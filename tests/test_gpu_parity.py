@@ -596,6 +596,30 @@ def test_device_order_search_edge_cases(ctx):
         assert np.array_equal(dev['S2'], S2h) and np.array_equal(dev['C'], Ch) and np.array_equal(dev['tau'], tauh)
 
 
+@pytest.mark.parametrize('N,Vtot,v0,nV,Npad', [
+    (1000, 32, 0, 32, 1024),          # one full tile column, last tile of frames partly past N
+    (1001, 50, 7, 37, 1280),          # nothing aligned: odd Vtot, odd first vector, 37 vectors (32 + 5), N % 4 = 1
+    (64, 3, 1, 1, 64),                # one vector
+    (130, 96, 32, 64, 192),           # two full vector tiles of a larger array
+    (4099, 33, 0, 33, 4352),          # padding of more than one tile of frames behind N: written as zeros
+])
+def test_pack_planes_bit_exact(ctx, N, Vtot, v0, nV, Npad):
+    """kernel 0 alone (sr_pack_soa_f32_dev): the planes are the vectors transposed, bit for bit, and every frame in [N, Npad) is
+    zero -- for shapes that are not multiples of the kernel's tile (64 frames x 32 vectors) or of four."""
+    import torch
+    rng = np.random.default_rng(N + Vtot)
+    vecs = rng.standard_normal((N, Vtot, 3)).astype(np.float32)
+    dev = torch.device('cuda', 0)
+    d = torch.from_numpy(vecs).to(dev)
+    soa = torch.full((nV, 3, Npad), float('nan'), device=dev, dtype=torch.float32)
+    ctx.set_stream(0)
+    ctx.pack_soa_dev(d.data_ptr(), N, Vtot, v0, nV, soa.data_ptr(), Npad)
+    torch.cuda.synchronize()
+    planes = soa.cpu().numpy()
+    assert np.array_equal(planes[:, :, :N], np.transpose(vecs[:, v0:v0 + nV], (1, 2, 0)))
+    assert not planes[:, :, N:].any()
+
+
 def test_per_frame_rotation_and_fused_detumbling(ctx):
     """SURVEY.md section 8(f)-1.  (a) sr_rotate_vectors_perframe_f32 against the reference's rotate_vector_simd run bond
     by bond with one quaternion per frame; (b) the de-tumbling folded into the pack kernel

@@ -88,10 +88,11 @@ __device__ __forceinline__ double wave_sum_f64(double v)
 constexpr int kPackFrames = 64;
 constexpr int kPackVecs = 32;
 
-// 16-byte accesses on both sides: a frame's 32 vectors are 96 consecutive floats (24 float4 when the row start is
+// The general form (any number of vectors, any alignment): a 64-frame x 32-vector tile transposed through LDS.
+// 16-byte accesses on both sides when it can: a frame's 32 vectors are 96 consecutive floats (24 float4 when the row start is
 // 16-byte aligned, i.e. Vtot*3 and (v0+vb)*3 multiples of 4), a plane row of 64 frames is 16 float4.
-__global__ __launch_bounds__(256) void k_pack_soa(const float *__restrict__ vecs, int64_t N, int64_t Vtot,
-                                                  int64_t v0, int64_t nV, float *__restrict__ soa, int64_t Npad)
+__global__ __launch_bounds__(256) void k_pack_soa_ragged(const float *__restrict__ vecs, int64_t N, int64_t Vtot,
+                                                         int64_t v0, int64_t nV, float *__restrict__ soa, int64_t Npad)
 {
     __shared__ float tile[kPackVecs * 3][kPackFrames + 1];
     const int64_t n0 = (int64_t)blockIdx.x * kPackFrames;
@@ -130,6 +131,56 @@ __global__ __launch_bounds__(256) void k_pack_soa(const float *__restrict__ vecs
             const float4 o = make_float4(tile[k][n], tile[k][n + 1], tile[k][n + 2], tile[k][n + 3]);
             *reinterpret_cast<float4 *>(soa + (vb * 3 + k) * Npad + fr) = o;
         }
+    }
+}
+
+// The production form (whole 32-vector tiles, 16-byte aligned rows: cfg3 / cfg4 and every shard of them): the transposition in
+// REGISTERS, no LDS.  A thread owns three 4 x 4 blocks -- four consecutive frames x one 16-byte column of a frame's row (four
+// consecutive components) -- twelve 16-byte loads all in flight, then twelve 16-byte stores; the lanes of a wave are 8 columns x 8
+// frame groups, so a wave-load reads 8 full 128-byte lines (8 frames) and a wave-store writes 8 full lines (128 B of each of 8
+// planes).  Both sides non-temporal: the vectors are read once, the planes are next read by another kernel.  Measured against the
+// LDS tile above (round 4, scripts/dev/interference.py, same box each time): alone 0.208-0.223 against 0.229-0.239 ms (5.5-5.9
+// TB/s), and what one pack costs 20 back-to-back C(t) launches it runs beside 0.165-0.185 against 0.197-0.207 ms; 20-step
+// benchmark 2.27-2.32 against 2.35-2.38 ms per step.  The LDS tile's scattered 4-byte LDS writes and its 54 instructions per 16
+// bytes were what the C(t) waves on the same CU paid for.  (An LDS-DMA fill of the same tile: no gain; 16 or 4 columns per wave,
+// temporal accesses, four loads in flight instead of twelve: worse or equal.)
+constexpr int kPackRegFrames = 128;
+__global__ __launch_bounds__(256) void k_pack_soa(const float *__restrict__ vecs, int64_t N, int64_t Vtot,
+                                                  int64_t v0, int64_t nV, float *__restrict__ soa, int64_t Npad)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int64_t n0 = (int64_t)blockIdx.x * kPackRegFrames;
+    const int64_t vb = (int64_t)blockIdx.y * kPackVecs;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 7, gl = lane >> 3;
+    v4f r[3][4];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int blk = it * 4 + wave;                        // 12 wave-blocks: 3 column groups x 4 groups of 8 frame groups
+        const int q = (blk % 3) * 8 + ql;                     // 16-byte column of the 96-float row
+        const int64_t fr = n0 + 4 * ((blk / 3) * 8 + gl);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                         // no branch around a load: past the end, frame N - 1 again
+            const int64_t f = min(fr + j, N - 1);
+            r[it][j] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(vecs + (f * Vtot + v0 + vb) * 3 + 4 * q));
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int blk = it * 4 + wave;
+        const int q = (blk % 3) * 8 + ql;
+        const int64_t fr = n0 + 4 * ((blk / 3) * 8 + gl);
+        if (fr >= Npad) continue;                             // Npad % 4 == 0: a frame group is inside the planes or outside
+        if (fr + 3 >= N) {                                    // frames in [N, Npad): zeros
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (fr + j >= N) r[it][j] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        float *o = soa + (vb * 3 + 4 * q) * Npad + fr;
+        __builtin_nontemporal_store(v4f{r[it][0].x, r[it][1].x, r[it][2].x, r[it][3].x}, reinterpret_cast<v4f *>(o));
+        __builtin_nontemporal_store(v4f{r[it][0].y, r[it][1].y, r[it][2].y, r[it][3].y}, reinterpret_cast<v4f *>(o + Npad));
+        __builtin_nontemporal_store(v4f{r[it][0].z, r[it][1].z, r[it][2].z, r[it][3].z}, reinterpret_cast<v4f *>(o + 2 * Npad));
+        __builtin_nontemporal_store(v4f{r[it][0].w, r[it][1].w, r[it][2].w, r[it][3].w}, reinterpret_cast<v4f *>(o + 3 * Npad));
     }
 }
 
@@ -1423,8 +1474,12 @@ int sr_pack_soa_f32_dev(sr_ctx *ctx, const float *vecs, int64_t N, int64_t Vtot,
     const int64_t gx = (Npad + kPackFrames - 1) / kPackFrames;
     const int64_t gy = (nV + kPackVecs - 1) / kPackVecs;
     SR_REQUIRE(gy <= 65535, -3, "sr_pack_soa_f32_dev: too many vectors in one call (%lld)", (long long)nV);
-    hipLaunchKernelGGL(k_pack_soa, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ctx->stream, vecs, N, Vtot, v0, nV,
-                       soa, Npad);
+    if (nV % kPackVecs == 0 && ((Vtot * 3) & 3) == 0 && ((v0 * 3) & 3) == 0 && (((uintptr_t)vecs | (uintptr_t)soa) & 15) == 0)
+        hipLaunchKernelGGL(k_pack_soa, dim3((unsigned)((Npad + kPackRegFrames - 1) / kPackRegFrames), (unsigned)gy), dim3(256), 0,
+                           ctx->stream, vecs, N, Vtot, v0, nV, soa, Npad);
+    else
+        hipLaunchKernelGGL(k_pack_soa_ragged, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ctx->stream, vecs, N, Vtot, v0, nV,
+                           soa, Npad);
     SR_HIP(hipGetLastError());
     return 0;
 }

@@ -600,12 +600,14 @@ def test_device_order_search_edge_cases(ctx):
     (1000, 32, 0, 32, 1024),          # one full tile column, last tile of frames partly past N
     (1001, 50, 7, 37, 1280),          # nothing aligned: odd Vtot, odd first vector, 37 vectors (32 + 5), N % 4 = 1
     (64, 3, 1, 1, 64),                # one vector
-    (130, 96, 32, 64, 192),           # two full vector tiles of a larger array
+    (130, 96, 32, 64, 192),           # two full vector tiles of a larger array (the register kernel, padding inside its tile)
+    (100, 64, 32, 32, 128),           # fewer frames than one tile of the register kernel
     (4099, 33, 0, 33, 4352),          # padding of more than one tile of frames behind N: written as zeros
 ])
 def test_pack_planes_bit_exact(ctx, N, Vtot, v0, nV, Npad):
     """kernel 0 alone (sr_pack_soa_f32_dev): the planes are the vectors transposed, bit for bit, and every frame in [N, Npad) is
-    zero -- for shapes that are not multiples of the kernel's tile (64 frames x 32 vectors) or of four."""
+    zero -- for whole aligned 32-vector tiles (k_pack_soa, registers) and for shapes that are not multiples of a tile or of four
+    (k_pack_soa_ragged, LDS tile)."""
     import torch
     rng = np.random.default_rng(N + Vtot)
     vecs = rng.standard_normal((N, Vtot, 3)).astype(np.float32)

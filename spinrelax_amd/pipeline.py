@@ -196,7 +196,9 @@ class DevicePipeline:
         # bursts hit the memory system while those workgroups prefetch.  On 96-160 CUs it still streams as fast as it needs
         # (0.33 ms in the pipeline either way) and half of the C(t) workgroups never meet it: steady state 2.13 -> 2.09 ms
         # per step (same box, alternating runs, two rounds each; 64 CUs: 2.17, 32: 2.6; the chunk-statistics stream
-        # confined as well: no further change).  CU bit i belongs to XCD i % 8, so a prefix of 8 k bits is k CUs per XCD.
+        # confined as well: no further change).  Measured with the LDS-tile pack of rounds 1-3; with the register pack (82 VGPRs, no
+        # LDS) 0 / 64 / 128 / 192 CUs are within the noise of each other and 128 stayed.
+        # CU bit i belongs to XCD i % 8, so a prefix of 8 k bits is k CUs per XCD.
         self.pack_cus = 0
         if pack_cus and aux_words is None and self.depth > 1:
             ncu = info['n_cu']

@@ -9,12 +9,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libspinrelax_hip.so')
-SOURCES = ['sr_core.hip', 'sr_ct.hip', 'sr_vechist.hip', 'sr_fit.hip', 'sr_relax.hip', 'sr_dq.hip', 'sr_traj.hip', 'sr_vectors.hip', 'sr_textio.hip']
+SOURCES = ['sr_core.hip', 'sr_ct.hip', 'sr_ct32.hip', 'sr_vechist.hip', 'sr_fit.hip', 'sr_relax.hip', 'sr_dq.hip', 'sr_traj.hip', 'sr_vectors.hip', 'sr_textio.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 # sr_ct.hip: the SLP vectoriser packs the FMAs of the C(t) inner loop into v_pk_fma_f32, whose operand pairs then
 # need ~1 v_mov per FMA (rocprofv3: 4.8e9 VALU instructions for 2.5e9 FMAs); plain v_fma_f32 issues at the same rate.
 EXTRA = {'sr_ct.hip': ['-fno-slp-vectorize'],
+         # sr_ct32.hip: the same for the float32 transforms (packed complex arithmetic by the vectoriser costs a v_mov per
+         # operand pair and 270 B of scratch at 128 VGPRs; without it 56 B)
+         'sr_ct32.hip': ['-fno-slp-vectorize'],
          # sr_fit.hip: explicit fma() only, see the note at the top of the file
          'sr_fit.hip': ['-ffp-contract=off']}
 if os.environ.get('SR_FIT_DEV_FAST'):          # development: only the order-search variants the benchmark uses

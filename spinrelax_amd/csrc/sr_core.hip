@@ -93,6 +93,7 @@ sr_ctx *sr_create(int device)
     ctx->ct_fft = 2;
     ctx->ct_traceless = 0;
     ctx->fft_table_ready = 0;
+    ctx->fft32_table_ready = 0;
     if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) {
         sr_set_error("hipGetDeviceProperties failed");
         delete ctx;
@@ -138,7 +139,7 @@ int sr_set_option(sr_ctx *ctx, const char *name, int value)
         return 0;
     }
     if (!strcmp(name, "ct_fft")) {
-        SR_REQUIRE(value >= 0 && value <= 2, -3, "sr_set_option: ct_fft must be 0, 1 or 2");
+        SR_REQUIRE(value >= 0 && value <= 3, -3, "sr_set_option: ct_fft must be 0, 1, 2 or 3");
         ctx->ct_fft = value;
         return 0;
     }

@@ -7,7 +7,7 @@
 #include <cstring>
 #include "../../include/spinrelax_hip.h"
 
-#define SR_NSLOTS 14
+#define SR_NSLOTS 15
 
 struct sr_ctx {
     int device;
@@ -24,6 +24,7 @@ struct sr_ctx {
                         // (default), 1 = complex FFT formulation (k_ct_fft) everywhere, 0 = always the direct kernel
     int ct_traceless;   // 1: k_ct_rfft<12> in its traceless five-signal form (faster alone, slower inside the pipeline: default 0)
     int fft_table_ready;
+    int fft32_table_ready;
     // strided host -> device copies of bond vectors (sr_vectors.hip): two pinned staging buffers, and what went through them
     void *stage[2];
     hipEvent_t stage_ev[2];
@@ -41,7 +42,8 @@ enum {
     SR_WS_IN0, SR_WS_IN1, SR_WS_IN2, SR_WS_IN3,
     SR_WS_MISC,
     SR_WS_FIT,          // residual work space of the fit kernel (when the caller passes none)
-    SR_WS_FFT           // twiddle table of the FFT formulation of kernel 1
+    SR_WS_FFT,          // twiddle table of the FFT formulation of kernel 1
+    SR_WS_FFT32         // tables of its float32 form (sr_ct32.hip)
 };
 
 void sr_set_error(const char *fmt, ...);
@@ -80,6 +82,10 @@ static inline size_t sr_lds_limit(const sr_ctx *ctx)
 int sr_grant_lds(sr_ctx *ctx, int kid, const void *func, size_t bytes);
 
 static inline int64_t sr_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// sr_ct32.hip: the float32 real-input FFT form of kernel 1 (raw lag sums per chunk, like k_ct_rfft); the chunk starts may be null
+int sr_launch_ct_rfft32(sr_ctx *ctx, const float *soa, int64_t Npad, const int64_t *cs_host, const int64_t *cs_dev, double *psum,
+                        int R, int F, int L, int Lp, int64_t series);
 
 #ifdef __HIPCC__
 // ---- wave-level float64 sum on the VALU only (DPP + readlane), no LDS round trips -----------------

@@ -150,7 +150,7 @@ def parse():
     ap.add_argument('--fit-lds', type=int, default=-1, help='1/0: keep residue data in LDS during the fits (-1 = library default)')
     ap.add_argument('--dev-skip-fits', action='store_true', help='DEVELOPMENT ONLY (invalid as a benchmark): leave the fits and the relaxation kernel out, to see the floor the C(t) side alone sets')
     ap.add_argument('--hist-on-main', action='store_true', help='keep the histogram kernel in line with C(t) (only the pack runs beside it)')
-    ap.add_argument('--ct-fft', type=int, default=-1, help='kernel 1: 2 = real-input FFT (k_ct_rfft) where it applies, 1 = complex FFT (k_ct_fft), 0 = direct (k_ct_palmer); -1 = library default (2)')
+    ap.add_argument('--ct-fft', type=int, default=-1, help='kernel 1: 3 = float32 real-input FFT (k_ct_rfft32) where it applies, 2 = float64 real-input FFT (k_ct_rfft), 1 = complex float64 FFT (k_ct_fft), 0 = direct (k_ct_palmer); -1 = library default (3)')
     ap.add_argument('--ct-traceless', type=int, default=0, help='1: k_ct_rfft<12> with five transforms (traceless components; library option ct_traceless, default off)')
     ap.add_argument('--group', type=int, default=32, help='batches whose fits / relaxation run as ONE merged launch behind their C(t) kernels (GroupedPipeline; a run of K steps uses groups of min(K, group)); 1 = every batch launches its own fits (DevicePipeline, --depth of them in flight)')
     ap.add_argument('--pack-cus', type=int, default=128, help='grouped schedule: CUs the pack stream is confined to (0 = all; the compute streams always have the whole chip)')
@@ -309,7 +309,22 @@ def cli_wall(vecs_host, s, cfg, cpu):
 
 
 def use_rfft_bench(args, s):
-    return args.ct_fft in (-1, 2) and 4096 < s['F'] + s['L'] <= 8192
+    return args.ct_fft in (-1, 2, 3) and 4096 < s['F'] + s['L'] <= 8192
+
+
+def use_rfft32_bench(args, s):
+    return args.ct_fft in (-1, 3) and 4096 < s['F'] + s['L'] <= 8192
+
+
+def fft32_exec_flop(s, V):
+    """float32 work per launch of k_ct_rfft32 by the textbook count (the committed PMC pass replaces it when it has the kernel):
+    5 forward + 1 back complex transforms of H = M/2 points (5 H log2 H flop each), two twiddle passes (6 flop per point), the
+    real-signal spectrum step (24 flop per frequency) for five signals, and per frame the signals (about 14 flop) twice (prologue
+    means, epilogue e[j])."""
+    need = s['F'] + s['L']
+    M = 6144 if need <= 6144 else 8192
+    H = M // 2
+    return M, s['R'] * V * (6 * (5 * H * np.log2(H) + 12 * H) + 5 * 24 * H + 60 * s['F'])
 
 
 def fft_exec_flop(s, V, real_input=False, traceless=False):
@@ -589,10 +604,13 @@ def main():
         if 1024 < s['F'] + s['L'] <= 8192 and args.ct_fft != 0:
             ctx.set_option('ct_fft', 0)
             alone['ct_direct'] = timed(lambda: p1.stage_ct(s0, finalize=False), reps=2)
-            if args.ct_fft in (-1, 2) and s['F'] + s['L'] > 4096:
+            if args.ct_fft in (-1, 2, 3) and s['F'] + s['L'] > 4096:
                 ctx.set_option('ct_fft', 1)                       # and the complex-FFT formulation it replaced, for reference
                 alone['ct_complex_fft'] = timed(lambda: p1.stage_ct(s0, finalize=False), reps=2)
-            ctx.set_option('ct_fft', 2 if args.ct_fft < 0 else args.ct_fft)
+                if use_rfft32_bench(args, s):
+                    ctx.set_option('ct_fft', 2)                   # the float64 real-input transform kernel (rounds 2-4's production kernel)
+                    alone['ct_rfft_f64'] = timed(lambda: p1.stage_ct(s0, finalize=False), reps=2)
+            ctx.set_option('ct_fft', 3 if args.ct_fft < 0 else args.ct_fft)
             with torch.cuda.stream(st1):
                 p1.stage_ct(s0)                 # restore the slot's sums / C(t) from the production kernel
         # the other real-input FFT variant (M = 8192: 4096 < F <= 5461) on the same planes, at two chunk lengths: its cost per
@@ -641,8 +659,9 @@ def main():
         triples_total = synth.exact_triples(s['R'], s['F'], Vtot)
         value = triples_total / (elapsed / args.steps)
         use_fft = (args.ct_fft != 0) and 1024 < s['F'] + s['L'] <= 8192
-        use_rfft = use_fft and args.ct_fft in (-1, 2) and s['F'] + s['L'] > 4096
-        kname = 'k_ct_rfft' if use_rfft else ('k_ct_fft' if use_fft else 'k_ct_palmer')
+        use_rfft = use_fft and args.ct_fft in (-1, 2, 3) and s['F'] + s['L'] > 4096
+        use_f32 = use_fft and use_rfft32_bench(args, s)
+        kname = 'k_ct_rfft32' if use_f32 else ('k_ct_rfft' if use_rfft else ('k_ct_fft' if use_fft else 'k_ct_palmer'))
         prof, prof_src = committed_profile() if cfg == 3 and V == 512 else ({}, None)
         stale, build_id = profile_staleness() if prof else (None, None)
         stale_txt = ' -- STALE: collected with library build %s, this run loaded build %s (re-run scripts/profile_round.sh)' % (PROFILE_BUILD_ID, build_id) if stale else ''
@@ -673,7 +692,28 @@ def main():
             kernels[name] = e
             return e
 
-        if use_fft:
+        if use_f32:
+            M, xflop = fft32_exec_flop(s, V)
+            xflop_formula = float(xflop)
+            pe = prof_entry(prof, kname)
+            xsrc = 'formula (bench.py:fft32_exec_flop)'
+            if pe and pe.get('fp32_flop_per_launch'):
+                xflop, xsrc = pe['fp32_flop_per_launch'], 'PMC float32 instruction counts of the committed profile %s%s' % (prof_src, stale_txt)
+            entry(kname, 'valu-fp32 (packed float32 vector arithmetic; LDS-exchange- and latency-limited)', xflop, 1e12, PEAK_FP32_TFLOPS, 'TFLOP/s',
+                  ct_ms, alone.get('ct'),
+                  formulation='Wiener-Khinchin on real input in the reference\'s arithmetic type: 5 + 1 FLOAT32 complex transforms of %d points on the '
+                              'mean-removed traceless components (packed v_pk_*_f32 complex arithmetic), the mean terms restored in float64 by one scan '
+                              'per series; three workgroups per CU (spinrelax_amd/csrc/sr_ct32.hip)' % (M // 2),
+                  work_source=xsrc, work_per_launch_textbook=xflop_formula, executed_over_textbook=float(xflop) / xflop_formula,
+                  algorithmic_bytes=12 * N * V + 8 * R * L * V,
+                  float64_transform_kernel_alone_ms=alone.get('ct_rfft_f64'),
+                  accuracy='C(t) 4e-8 relative, dC(t) 3e-9 absolute against the float64 oracle on this workload (tests/test_gpu_pipeline.py); the reference itself computes C(t) in float32',
+                  note='in the pipeline the kernel is confined to %d of %d CUs' % (N_CU - reserve_used, N_CU))
+            if alone.get('ct_direct'):
+                entry('k_ct_palmer', 'valu-fp32 (non-MFMA vector FMA; FP32 MFMA peak is the same)', 8.0 * triples, 1e12, PEAK_FP32_TFLOPS, 'TFLOP/s',
+                      None, alone['ct_direct'], formulation='direct shifted products, 8 flop per (frame, vector, lag) triple (SURVEY 8(d)); second line, timed alone',
+                      algorithmic_bytes=12 * N * V + 8 * R * L * V)
+        elif use_fft:
             M, xflop = fft_exec_flop(s, V, use_rfft, bool(args.ct_traceless))
             xflop_formula = float(xflop)
             pe = prof_entry(prof, kname)
@@ -807,7 +847,9 @@ def main():
             'steady_note': 'one run of %d steps, fill and drain amortised; not the headline' % args.steady_steps,
             'spinup': {'seconds': spin_s, 'steps': spin_steps, 'note': 'untimed steps of the same pipeline before the warm-up steps (clock ramp of a fresh box)'},
             'latency_ms': latency, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
-            'dtype': 'f64 (C(t) by FFT on f32 inputs; histogram, fit, J(w), R1/R2/NOE)' if use_fft else 'f32 dot products / f64 accumulation (C(t)); f64 (histogram, fit, J(w), R1/R2/NOE)',
+            'dtype': ('f32 transforms + f64 mean terms and chunk statistics (C(t): the reference\'s own type); f64 (histogram, fit, J(w), R1/R2/NOE)' if use_f32 else
+                      'f64 (C(t) by FFT on f32 inputs; histogram, fit, J(w), R1/R2/NOE)' if use_fft else
+                      'f32 dot products / f64 accumulation (C(t)); f64 (histogram, fit, J(w), R1/R2/NOE)'),
             'data': 'synthetic',
             'config': {'workload': 'BASELINE cfg%d%s: %d frames x %d vectors%s, %d chunks x %d frames, %d lags, '
                                    '%s, fits 2/3/5/7/9 params, 1 field' % (cfg, '' if strong else ' per GPU', s['frames'], Vtot if strong else V,

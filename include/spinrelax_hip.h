@@ -53,8 +53,9 @@ int          sr_sync(sr_ctx *);
 /* Tuning knobs: "fit_waves" = wavefronts per residue in the fits (1, 2 or 4; default 4: with the chip full of fits
  * all three cost the same per residue and 4 has the shortest launch (1.6x and 2.8x shorter than 2 and 1 on the
  * 512-residue benchmark batch); results are bit-identical only between runs with the same value), "fit_lds" = 1/0 keep
- * a residue's t, C(t), 1/sigma in LDS, "ct_fft" = formulation of kernel 1 where the chunk length allows: 2 (default) the
- * real-input FFT for 4096 < F + L <= 8192 and the complex FFT below, 1 the complex FFT everywhere, 0 always direct;
+ * a residue's t, C(t), 1/sigma in LDS, "ct_fft" = formulation of kernel 1 where the chunk length allows: 3 (default) the
+ * FLOAT32 real-input FFT for 4096 < F + L <= 8192 (the reference's own arithmetic type; C(t) to 4e-8) and the float64 complex
+ * FFT below, 2 the float64 real-input FFT in that range (C(t) to 1e-15), 1 the float64 complex FFT everywhere, 0 always direct;
  * "ct_traceless" = 1/0 (default 0): the real-input FFT kernel for F <= 4096 transforms the five traceless components of
  * u (x) u and takes the trace term from a scan of |u|^2 - 1 (one transform fewer; series that are not unit vectors fall back
  * to six inside the kernel) -- 4 % faster alone, 3 % slower per step inside the pipeline, same results to 1e-13. */
@@ -116,9 +117,12 @@ int sr_pack_soa_rot_f32_dev(sr_ctx *, const float *vecs, int64_t N, int64_t Vtot
  *     Ct[d-1,v]   = mean_r p ;   dCt[d-1,v] = std_r(p, ddof=0) / (sqrt(R) - 1)
  * Ct, dCt are (L, nV) float64, row-major -- the reference's (nDeltas, nResidues).
  * mode 0 (production): the fastest formulation for the chunk length --
- *           1024 < F + L <= 8192: the six autocorrelations of (x^2, y^2, z^2, xy, xz, yz) by float64 FFT
- *           (Wiener-Khinchin, (u.u')^2 = sum_c w_c a_c a_c'), one workgroup per (chunk, vector) with the whole
- *           2048/4096/8192-point transform in LDS; accurate to ~1e-15;  sr_set_option("ct_fft", 0) disables it;
+ *           1024 < F + L <= 8192: Wiener-Khinchin, (u.u')^2 = sum_c w_c a_c a_c' with a_c products of two components, one
+ *           workgroup per (chunk, vector) with the whole transform in LDS.  4096 < F + L <= 8192 (cfg3 / cfg4): float32
+ *           transforms of the five mean-removed traceless components, the mean terms restored in float64 (k_ct_rfft32:
+ *           C(t) to ~4e-8, the class of the direct kernel and of the reference's own float32); shorter chunks: float64
+ *           transforms (~1e-15).  sr_set_option("ct_fft", 2) selects float64 transforms everywhere, 0 disables the
+ *           formulation;
  *           otherwise: direct shifted products, float32 dot products and short float32 partial sums folded into
  *           float64 (accurate to ~1e-8);
  * mode 1: direct shifted products, every product and sum in float64 (validation path).

@@ -90,7 +90,7 @@ sr_ctx *sr_create(int device)
     ctx->stream = nullptr;
     ctx->fit_waves = 4;
     ctx->fit_lds = 1;
-    ctx->ct_fft = 2;
+    ctx->ct_fft = 3;
     ctx->ct_traceless = 0;
     ctx->fft_table_ready = 0;
     ctx->fft32_table_ready = 0;

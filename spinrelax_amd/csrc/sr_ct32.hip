@@ -451,7 +451,8 @@ SR_PK c32 f32_sig5(c32 x, c32 y, c32 z, float m) { return pk_fma(z, z, pk_fma(x,
 #define SR_CT32_PF 0
 #endif
 #ifndef SR_CT32_WAVES
-#define SR_CT32_WAVES 4          // waves per SIMD the N1 = 12 kernel is compiled for (register budget 128)
+#define SR_CT32_WAVES 3          // waves per SIMD the N1 = 12 kernel is compiled for: 156 VGPRs, no scratch (4: 128 VGPRs and 72 B of
+                                 // scratch reloaded inside the transform loop -- 0.64 against 0.55 ms)
 #endif
 // FULL: the chunk fills the loaded input blocks exactly (F = 512 NZ) and frames 2m, 2m + 1 share an aligned 8 bytes: no
 // frame masks, 8-byte loads only (cfg3 / cfg4: F = 4096 with N1 = 12).

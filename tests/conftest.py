@@ -90,3 +90,19 @@ def committed_tally(section, key, measured):
         if dump:                      # first collection of a new entry: nothing committed to hold it to yet
             return measured
         raise
+
+
+def ct_f32_transform(F):
+    """True when the production dispatch of kernel 1 (ct_fft = 3) runs FLOAT32 transforms for this chunk length
+    (k_ct_rfft32, sr_ct32.hip): 4096 < F + L <= 8192.  Its bars: C(t) 1e-7 relative; the replicate means p_r it feeds into dC(t)
+    5e-8 absolute (measured 3e-8: the rounding of a float32 transform does not average down with the chunk length the way the
+    direct kernel's per-product rounding does), i.e. |d dC(t)| <= 5e-8 / (sqrt(R) - 1)."""
+    return 4096 < F + F // 2 <= 8192
+
+
+def dct_close_f32_transform(dCt, ref, R, Ct=None):
+    """Ct: the C(t) values, for series that are not unit vectors (C(t) then is not bounded by 1 and the absolute bar scales
+    with it, per vector)"""
+    import numpy as np
+    scale = 1.0 if Ct is None else np.maximum(1.0, np.max(np.abs(Ct), axis=0))[None, :]
+    return bool(np.all(np.abs(dCt - ref) <= np.maximum(1e-6 * np.abs(ref), scale * 5e-8 / (np.sqrt(R) - 1.0))))

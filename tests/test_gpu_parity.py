@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, golden, relerr
+from conftest import ROOT, golden, relerr, ct_f32_transform, dct_close_f32_transform
 import sr_oracle as o
 from spinrelax_amd import synth
 
@@ -112,24 +112,83 @@ def test_ct_ragged_and_edge_sizes(ctx, liboracle, F, R, V):
             assert dct_close(dCt, dCr, R, F)
 
 
+@pytest.mark.parametrize('ct_fft', [3, 2])
 @pytest.mark.parametrize('F,R,V', [(683, 2, 3), (684, 2, 3), (1365, 3, 2), (1366, 2, 2), (2000, 2, 3), (2730, 2, 2), (2731, 2, 2),
                                    (3000, 2, 2), (4096, 2, 3), (4097, 2, 2), (5000, 2, 2), (5461, 2, 1), (5462, 2, 1)])
-def test_ct_fft_formulation_all_transform_sizes(ctx, liboracle, F, R, V):
+def test_ct_fft_formulation_all_transform_sizes(ctx, liboracle, F, R, V, ct_fft):
     """The FFT formulation of kernel 1 (default for 1024 < F + L <= 8192) at every transform size and on both sides of
     every switch: 2048 / 4096 / 8192 points, chunks that fill at most half of the transform (upper half skipped) and
     chunks that do not, the last length that fits (5461) and the first that falls back to the direct kernel (5462).
-    Checked against the plain-C float64 oracle; the FFT path must be at float64 accuracy, far inside the 1e-6 bar."""
+    Checked against the plain-C float64 oracle.  ct_fft = 2: float64 transforms everywhere, float64 accuracy.  ct_fft = 3 (the
+    default): FLOAT32 transforms for 4096 < F + L <= 8192 (k_ct_rfft32: F = 2731 .. 5461 here), within the float32 bars."""
     vecs = synth.synth_vectors(R * F + 5, V, seed=300 + F)
     v4 = vecs[:R * F].reshape(R, F, V, 3)
     Cr, dCr = c_oracle_ct(liboracle, v4)
-    Ct, dCt = ctx.ct_palmer(vecs, R, F)
+    ctx.set_option('ct_fft', ct_fft)
+    try:
+        Ct, dCt = ctx.ct_palmer(vecs, R, F)
+        Ct1, dCt1 = ctx.ct_palmer(vecs, R, F, mode=1)            # the direct float64 mode
+    finally:
+        ctx.set_option('ct_fft', 3)
     assert Ct.shape == (F // 2, V)
     uses_fft = 1024 < F + F // 2 <= 8192
-    assert relerr(Ct, Cr) < (1e-12 if uses_fft else RTOL)
-    assert np.max(np.abs(dCt - dCr)) <= (1e-12 if uses_fft else 1e-6) * max(1.0, np.max(np.abs(dCr)))
-    # same answer from the direct float64 mode
-    Ct1, dCt1 = ctx.ct_palmer(vecs, R, F, mode=1)
-    assert relerr(Ct, Ct1) < (1e-12 if uses_fft else RTOL)
+    if uses_fft and ct_fft == 3 and ct_f32_transform(F):
+        assert relerr(Ct, Cr) < 1e-7 and dct_close_f32_transform(dCt, dCr, R)
+        assert relerr(Ct, Ct1) < 1e-7
+    else:
+        assert relerr(Ct, Cr) < (1e-12 if uses_fft else RTOL)
+        assert np.max(np.abs(dCt - dCr)) <= (1e-12 if uses_fft else 1e-6) * max(1.0, np.max(np.abs(dCr)))
+        assert relerr(Ct, Ct1) < (1e-12 if uses_fft else RTOL)
+
+
+def test_ct_rfft32_float32_transforms(ctx, liboracle):
+    """k_ct_rfft32 (sr_ct32.hip), the production kernel of cfg3 / cfg4: float32 transforms of the mean-removed traceless
+    components, mean terms restored in float64.  Against the plain-C float64 oracle on every path of the kernel: the aligned
+    full-chunk form (F = 4096), masked chunks (F < 4096, odd F), the 8192-point transform, odd chunk starts (32-bit loads),
+    series that are not unit vectors (the sixth signal |u|^2: scaled vectors, zero vectors of vecnorm_NDarray's 0/0 guard, one frame
+    just outside the unit tolerance), constant vectors, and the series of one launch mixed.  Bars: C(t) 1e-7 relative (measured
+    2-5e-8), dC(t) 5e-8 / (sqrt(R) - 1) absolute (conftest.dct_close_f32_transform)."""
+    worst = 0.0
+    for F, R, V in ((4096, 3, 6), (4000, 3, 2), (3001, 3, 2), (2732, 4, 2), (4094, 2, 2), (4097, 3, 2), (5000, 3, 2), (5333, 2, 2), (5461, 2, 1)):
+        vecs = synth.synth_vectors(R * F + 7, V, seed=500 + F).copy()
+        if V >= 2:
+            vecs[:, 1] *= np.float32(1.7)                               # not unit: whole series scaled
+        if V >= 6:
+            vecs[100:140, 2] = 0.0                                      # a few zero vectors (0/0 guard)
+            vecs[:, 3] *= (1.0 + 0.2 * np.sin(np.arange(vecs.shape[0]) / 50.0)).astype(np.float32)[:, None]
+            vecs[F + 5, 4] *= np.float32(1.0 + 2e-6)                    # one frame of one chunk just outside the tolerance
+        Cr, dCr = c_oracle_ct(liboracle, vecs[:R * F].reshape(R, F, V, 3))
+        Ct, dCt = ctx.ct_palmer(vecs, R, F)
+        e = relerr(Ct, Cr)
+        worst = max(worst, e)
+        assert e < 1e-7 and dct_close_f32_transform(dCt, dCr, R, Cr), (F, R, e, np.max(np.abs(dCt - dCr)))
+    print('\n[k_ct_rfft32] worst C(t) relative error over the shapes: %.2e' % worst)
+    # odd chunk starts (two "files" whose first one has an odd number of frames)
+    F = 4096
+    a = synth.synth_vectors(2 * F + 1, 3, seed=78)
+    b = synth.synth_vectors(F + 9, 3, seed=79)
+    cat = np.ascontiguousarray(np.concatenate([a, b]))
+    starts = np.array([0, F, 2 * F + 1], dtype=np.int64)
+    Cr, dCr = c_oracle_ct(liboracle, np.stack([cat[st:st + F] for st in starts]))
+    Ct, dCt = ctx.ct_palmer(cat, 3, F, chunk_start=starts)
+    assert relerr(Ct, Cr) < 1e-7 and dct_close_f32_transform(dCt, dCr, 3)
+    # constant unit vectors: every mean-removed signal is identically zero, C(t) = 1 comes out of the float64 mean terms alone
+    const = np.zeros((2 * F, 3, 3), dtype=np.float32)
+    const[:, 0, 0] = 1.0
+    const[:, 1, 1] = 1.0
+    const[:, 2, 2] = -1.0
+    Ct4, dCt4 = ctx.ct_palmer(const, 2, F)
+    assert np.max(np.abs(Ct4 - 1.0)) <= 4e-15 and np.max(np.abs(dCt4)) <= 4e-15
+    # same answer as the float64 transform kernel on the cfg3 slice, to the float32 bar
+    s = synth.config_shapes(3)
+    v3 = synth.synth_config(3, nvec=8)
+    C3, D3 = ctx.ct_palmer(v3, s['R'], s['F'])
+    ctx.set_option('ct_fft', 2)
+    try:
+        C2, D2 = ctx.ct_palmer(v3, s['R'], s['F'])
+    finally:
+        ctx.set_option('ct_fft', 3)
+    assert relerr(C3, C2) < 1e-7 and dct_close(D3, D2, s['R'], s['F'])
 
 
 def test_ct_multi_file_chunk_starts(ctx, liboracle):
@@ -181,7 +240,7 @@ def test_ct_size_independent_properties(ctx):
     assert np.max(np.abs(Ct4 - 1.0)) <= 4e-15 and np.max(np.abs(dCt4)) <= 4e-15
     ctx.set_option('ct_fft', 0)
     Ct5, dCt5 = ctx.ct_palmer(const, s['R'], s['F'])
-    ctx.set_option('ct_fft', 2)          # the library default: later tests of this module run the production dispatch
+    ctx.set_option('ct_fft', 3)          # the library default: later tests of this module run the production dispatch
     np.testing.assert_array_equal(Ct5, 1.0)
     np.testing.assert_array_equal(dCt5, 0.0)
     # (4) C(t) of a unit vector is bounded: -0.5 <= C <= 1
@@ -195,6 +254,7 @@ def test_ct_rfft_traceless_form_and_its_fallback(ctx, liboracle):
     is a float32 unit vector; any other series (scaled vectors, the zero vectors vecnorm_NDarray's 0/0 guard produces)
     takes the sixth transform on |u|^2.  Both must agree with the plain-C float64 oracle at float64 accuracy, also with
     chunk starts that are odd (unaligned 8-byte pairs: the 32-bit load path) and with the series of one launch mixed."""
+    ctx.set_option('ct_fft', 2)             # the float64 real-input kernel (the default dispatch runs k_ct_rfft32 at this length)
     ctx.set_option('ct_traceless', 1)
     try:
         F, R, V = 4096, 3, 6
@@ -235,6 +295,7 @@ def test_ct_rfft_traceless_form_and_its_fallback(ctx, liboracle):
         assert relerr(Ct0, Cr) < 1e-12 and relerr(Ct0, Ct) < 1e-12
     finally:
         ctx.set_option('ct_traceless', 0)
+        ctx.set_option('ct_fft', 3)
 
 
 def test_ct_rejects_bad_arguments(ctx):

@@ -420,8 +420,12 @@ def test_full_size_cfg3_values_against_the_oracle(full_cfg3):
     del v4
     eC = np.max(np.abs(st['Ct'] - Cr) / np.abs(Cr))
     eD = np.max(np.abs(st['dCt'] - dCr) / np.abs(dCr))
-    print('\n[cfg3, all 512 vectors] C(t) max rel err %.2e, dC(t) %.2e (%d x %d values each)' % (eC, eD, L, V))
-    assert eC < 1e-12 and eD < 1e-9
+    eDa = np.max(np.abs(st['dCt'] - dCr))
+    print('\n[cfg3, all 512 vectors] C(t) max rel err %.2e, dC(t) %.2e relative, %.2e absolute (%d x %d values each)' % (eC, eD, eDa, L, V))
+    # the production kernel of this chunk length runs float32 transforms (k_ct_rfft32): the float32 bars of the direct path --
+    # C(t) 1e-7, dC(t) 1e-6 / sqrt(F/2) / (sqrt(R) - 1) = 5.7e-9 absolute (tests/test_gpu_parity.py:dct_close); measured 5e-8, 3e-9
+    assert eC < 1e-7
+    assert np.all(np.abs(st['dCt'] - dCr) <= np.maximum(1e-6 * np.abs(dCr), 1e-6 / np.sqrt(F / 2.0) / (np.sqrt(R) - 1.0)))
     assert np.array_equal(st['y'], st['Ct'].T) and np.array_equal(st['dy'], st['dCt'].T)
     q = np.array(synth.Q_EXT)
     hist = st['hist'].reshape(V, 72, 36)
@@ -576,7 +580,7 @@ def test_bench_json_contract():
         assert k in r, k
     # every fraction is a fraction of a bound its kernel can reach: in (0, 1]
     ks = j['kernels']
-    assert r['kernel'] in ks and set(ks) >= {'k_ct_rfft', 'k_ct_palmer', 'k_vechist', 'k_pack_soa', 'k_order_search'}
+    assert r['kernel'] in ks and set(ks) >= {'k_ct_rfft32', 'k_ct_palmer', 'k_vechist', 'k_pack_soa', 'k_order_search'}
     top = ks[r['kernel']]
     assert top['cu_ms_per_batch'] == max(v['cu_ms_per_batch'] for k, v in ks.items() if k != 'k_ct_palmer')
     for name, e in ks.items():
@@ -585,7 +589,8 @@ def test_bench_json_contract():
                 assert 0 < e[f] <= 1.0, (name, f, e[f])
     if r['frac'] is not None:
         assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0 < r['frac'] <= 1
-    ct = ks['k_ct_rfft']
+    ct = ks['k_ct_rfft32']               # the production kernel of this chunk length: float32 transforms, FP32 vector peak
+    assert 'fp32' in ct['bound'] and ct['peak'] == 157.3 and 'f32' in j['dtype'] and ct['float64_transform_kernel_alone_ms'] > ct['alone_ms']
     # (two C(t) launches of consecutive batches overlap each other and the fits: a launch LASTS longer than a step)
     assert 0 < ct['in_pipeline_ms'] < j['ms_per_step'] * 3 and ct['alone_ms'] <= ct['in_pipeline_ms'] * 1.05
     assert abs(ct['frac'] - ct['work_per_launch'] / (ct['in_pipeline_ms'] * 1e-3) / 1e12 / ct['peak']) < 1e-9

@@ -158,6 +158,8 @@ def parse():
     ap.add_argument('--late-hist', type=int, default=1, help='grouped schedule: 1 = the histograms of a group run in the tail of its merged fit launch (released by the signal the launch\'s last workgroup writes; the planes of group + 3 batches stay alive), 0 = beside the C(t) kernels')
     ap.add_argument('--no-group-overlap', action='store_true', help='grouped schedule: the next group\'s C(t) kernels wait for the merged fit launch (strict phases)')
     ap.add_argument('--no-permute', action='store_true', help='grouped schedule: dispatch the merged launch in natural residue order')
+    ap.add_argument('--dispatch', type=str, default='history', choices=['history', 'random'],
+                    help='grouped schedule, order of the merged launch\'s residues: history = longest first by the evaluation counts of the last collected batch (a prediction; exact here because the benchmark repeats one shard -- the random-order figure is reported beside the headline), random = fixed pseudo-random order')
     ap.add_argument('--depth', type=int, default=5, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cli-wall', action='store_true', help='skip the wall-clock run of the drop-in CLI chain (run-all.bash Step 3 + Step 4) on the same workload')
@@ -410,6 +412,7 @@ def main():
                                stream=torch.cuda.Stream(device=dev, priority=args.main_priority),
                                **({} if args.late_hist else {'plane_buffers': args.plane_buffers}), **pkw)
         pipe.permute = not args.no_permute
+        pipe.dispatch = args.dispatch
         pipe.dev_skip_fits = bool(args.dev_skip_fits)
     else:
         pipe = DevicePipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], depth=args.depth,
@@ -499,6 +502,18 @@ def main():
             torch.cuda.synchronize()
             samples.append(time.perf_counter() - t0)
         nfev_timed = pipe.nfev_total - nfev0
+        # the same timed region with the prediction switched off (pseudo-random dispatch order of the merged launch), once: what a
+        # stream of unrelated trajectories would see
+        random_dispatch = None
+        if grouped and args.dispatch == 'history' and not args.no_permute:
+            pipe.dispatch = 'random'
+            run_batches(args.steps)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_batches(args.steps)
+            random_dispatch = (time.perf_counter() - t0) / args.steps
+            pipe.dispatch = 'history'
+            run_batches(args.steps)                   # (re-establishes the history for what follows)
         # steady state: one long run, fill and drain amortised (reported beside the headline, never as it)
         steady = None
         if args.steady_steps > 0:
@@ -508,10 +523,11 @@ def main():
             steady = (time.perf_counter() - t0) / args.steady_steps
 
     if world > 1:                  # every repeat: the slowest rank's time
-        tmax = torch.tensor(samples + [steady or 0.0], device=dev, dtype=torch.float64)
+        tmax = torch.tensor(samples + [steady or 0.0, random_dispatch or 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        samples = [float(x) for x in tmax[:-1].tolist()]
-        steady = float(tmax[-1].item()) if steady else None
+        samples = [float(x) for x in tmax[:-2].tolist()]
+        steady = float(tmax[-2].item()) if steady else None
+        random_dispatch = float(tmax[-1].item()) if random_dispatch else None
     elapsed = float(np.median(samples))
     if args.dev_no_events:
         ct_ms = hist_ms = fit_ms = float('nan')
@@ -561,6 +577,7 @@ def main():
     depth_used, reserve_used = pipe.depth, pipe.reserve_cus
     pack_cus_used = getattr(pipe, 'pack_cus', 0) or 256
     group_used = min(args.group, args.steps) if grouped else 1
+    late_hist_used, late_hist_note = bool(getattr(pipe, 'late_hist', False)), getattr(pipe, 'late_hist_note', None)
     listDoG = pipe.listDoG
     del events, gbuf
     pipe.close()
@@ -843,6 +860,10 @@ def main():
             'ms_per_step': ms_per_step, 'timed_region_samples_ms_per_step': [x / args.steps * 1e3 for x in samples],
             'timed_region_note': 'the timed region (exactly %d steps between two synchronisations, fill and drain inside) was run %d times; '
                                  'value and ms_per_step are the median' % (args.steps, len(samples)),
+            'ms_per_step_random_dispatch': None if random_dispatch is None else random_dispatch * 1e3,
+            'dispatch_note': 'the merged fit launch of a group takes its residues longest first by the evaluation counts of the last collected batch '
+                             '(spinrelax_amd/pipeline.py:GroupedPipeline, dispatch = history): a prediction, exact in this benchmark because every step is the '
+                             'same shard; ms_per_step_random_dispatch is the same timed region (once) with the fixed pseudo-random order of rounds 3-4',
             'ms_per_step_steady': None if steady is None else steady * 1e3,
             'steady_note': 'one run of %d steps, fill and drain amortised; not the headline' % args.steady_steps,
             'spinup': {'seconds': spin_s, 'steps': spin_steps, 'note': 'untimed steps of the same pipeline before the warm-up steps (clock ramp of a fresh box)'},
@@ -859,12 +880,13 @@ def main():
                        'sharding': 'contiguous vector ranges (spinrelax_amd/dist.py:shard_range; no data-path collective; all-gather of results)',
                        'schedule': ('grouped: pack / C(t) / chunk statistics%s of %d batches back to back, then ONE merged model-order search + '
                                     'relaxation launch over their %d residues (dispatched in a fixed pseudo-random order)%s; next group%s'
-                                    % ('' if args.late_hist else ' / histogram', group_used, group_used * V,
-                                       ', their histograms in the tail of that launch (released by a signal its last workgroup writes)' if args.late_hist else '',
+                                    % ('' if late_hist_used else ' / histogram', group_used, group_used * V,
+                                       ', their histograms in the tail of that launch (released by a signal its last workgroup writes)' if late_hist_used else '',
                                        ' overlaps it' if not args.no_group_overlap else ' waits for it'))
                                    if grouped else 'per batch: every batch launches its own fits, %d batches in flight' % depth_used,
                        'batches_per_group': group_used, 'batches_in_flight': group_used if grouped else depth_used, 'cus_reserved_for_fits': reserve_used,
-                       'pack_stream_cus': pack_cus_used},
+                       'pack_stream_cus': pack_cus_used, 'late_hist': late_hist_used, 'late_hist_note': late_hist_note,
+                       'dispatch': args.dispatch if grouped and not args.no_permute else 'natural'},
             'roofline': roofline,
             'kernels': kernels,
             'stages_alone_ms': {k: round(v, 4) for k, v in alone.items()},

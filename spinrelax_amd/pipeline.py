@@ -620,6 +620,9 @@ class _Group:
         self._ctx = ctx
         self.h_dres, self._h_dres_addr = _pinned_array(ctx, nd, np.float64)
         self.h_ires, self._h_ires_addr = _pinned_array(ctx, ni, np.int32)
+        # dispatch order of the merged launch: pinned host copy + device copy (refreshed per launch, stream-ordered before it)
+        self.h_order, self._h_order_addr = _pinned_array(ctx, GV, np.int32)
+        self.order_dev = torch.empty((GV,), **i32)
         self.stream = stream
         self.g = 0                 # batches of the group in flight / last collected
         self.first = 0             # index (in the run) of the group's first batch
@@ -725,12 +728,12 @@ class _Group:
         return out
 
     def release(self):
-        for name in ('_h_dres_addr', '_h_ires_addr'):
+        for name in ('_h_dres_addr', '_h_ires_addr', '_h_order_addr'):
             addr = getattr(self, name, None)
             if addr:
                 self._ctx.host_free(addr)
                 setattr(self, name, None)
-        self.h_dres = self.h_ires = None
+        self.h_dres = self.h_ires = self.h_order = None
 
 
 class GroupedPipeline(DevicePipeline):
@@ -750,10 +753,17 @@ class GroupedPipeline(DevicePipeline):
     and their workgroups (256 VGPRs) time-share the CUs with the C(t) grids: measured 2.28 ms per batch in steady state
     against 1.15 ms (phase 1 alone) + 0.71 ms (fits with the chip to themselves).  Merged over a group, the stragglers of
     all its batches run side by side while the cheap residues fill the rest of the chip.  The residues of the merged
-    launch are dispatched in a fixed pseudo-random order: residues that are expensive for the same reason sit at the
-    same index in every batch, and consecutive workgroup indices are served by the same part of the chip (natural
-    order: 32 ms for 20 batches; permuted: 21.5 ms).  Results are those of DevicePipeline bit for
-    bit (a residue's fit does not depend on what else is in the launch).
+    launch are dispatched LONGEST FIRST by prediction (`dispatch = 'history'`, the default): a residue's cost is taken to be
+    the number of model evaluations its fits needed in the most recent batch the pipeline has collected -- the shards of a
+    stream are consecutive pieces of one protein's trajectory, the residue whose nine-parameter fit crawls along a flat valley
+    in one shard is the likely straggler of the next -- and ties keep a fixed pseudo-random order (residues that are
+    expensive for the same reason sit at the same index in every batch, and consecutive workgroup indices are served by the
+    same part of the chip).  A launch lasts as long as its slowest residue: started first, the 14 ms fit ends with the bulk
+    instead of 14 ms after its random place in it.  A wrong prediction costs what the random order costs; results are those
+    of DevicePipeline bit for bit either way (a residue's fit does not depend on what else is in the launch).  `dispatch =
+    'random'`: the pseudo-random order alone (rounds 3-4); natural order: 32 ms for 20 batches, random 21.5 ms (DESIGN.md
+    section 5).  NOTE for readers of the benchmark: bench.py feeds the same shard every step, so there the prediction is exact;
+    it reports the random-order figure beside the headline.
 
     The next group's phase 1 is queued behind the merged launch without waiting for it (`overlap`), so the tail of one
     group's stragglers is covered by the next group's C(t) kernels; two group buffers alternate.  With `late_hist` that
@@ -782,13 +792,20 @@ class GroupedPipeline(DevicePipeline):
                                        % (max(1, int(group)) + 3, need / 1e9, free / 1e9))
         if self.late_hist:
             kw['plane_buffers'] = max(1, int(group)) + 3
+        else:
+            # the histograms then run on the auxiliary stream beside the C(t) kernels: a CU mask on that stream (meant for the pack
+            # alone) would confine them too, which measured slower -- no mask in this configuration
+            kw['pack_cus'] = 0
         for name in ('reserve_cus', 'aux_cus'):
             if kw.get(name):
                 raise ValueError('GroupedPipeline runs its phases on the whole chip: %s is not supported' % name)
         super().__init__(ctx, device, frames, V, R, F, dt, **kw)
         self.group = max(1, int(group))
         self.overlap = bool(overlap)
-        self.permute = True            # dispatch the merged launch's residues in a fixed pseudo-random order
+        self.permute = True            # False: dispatch the merged launch's residues in natural order
+        self.dispatch = 'history'      # 'history': longest first by the evaluation counts of the last collected batch; 'random'
+        self._cost = None              # (V,) evaluations per residue (all orders) of the most recent collected batch
+        self._cost_version = 0
         self.dev_skip_fits = False     # development only
         import os as _os
         self.dev_skip_hist = bool(_os.environ.get('SR_DEV_SKIP_HIST'))      # development only: marginal cost of the histogram in phase 1
@@ -812,8 +829,13 @@ class GroupedPipeline(DevicePipeline):
         except SpinRelaxHipError:
             # a device / runtime without stream waits on memory values: the histograms run beside the C(t) kernels instead
             for grp in self.groups:
+                if grp.signal:                        # the first allocation may have succeeded
+                    ctx.signal_free(grp.signal)
                 grp.signal = None
             if self.late_hist:
+                for grp in self.groups:               # pinned mirrors and streams of the group buffers
+                    grp.stream = None
+                    grp.release()
                 self.slots = self.pool
                 super().close()
                 raise SpinRelaxHipError('late_hist needs sr_signal_alloc (hipStreamWaitValue32 on signal memory); construct the '
@@ -859,12 +881,18 @@ class GroupedPipeline(DevicePipeline):
         return out
 
     def _dispatch_order(self, g):
-        """fixed pseudo-random permutation of the g V residues of a merged launch (device int32)"""
-        if g not in self._perm:
+        """order in which the workgroups of a merged launch take the g V residues (host int32 array): a fixed pseudo-random
+        permutation, stably re-sorted longest first by the predicted cost when there is a history (see the class comment)"""
+        hist = self.dispatch == 'history' and self._cost is not None
+        key = (g, self._cost_version if hist else -1)
+        if key not in self._perm:
             n = g * self.V
             p = np.random.RandomState(20240 + g).permutation(n).astype(np.int32) if g > 1 else np.arange(n, dtype=np.int32)
-            self._perm[g] = torch.from_numpy(p).to(self.dev)
-        return self._perm[g]
+            if hist:
+                p = p[np.argsort(-self._cost[p % self.V], kind='stable')]
+            self._perm = {k: v for k, v in self._perm.items() if k[1] == -1}       # older histories are dead
+            self._perm[key] = np.ascontiguousarray(p, dtype=np.int32)
+        return self._perm[key]
 
     def _fcsa_for(self, g):
         if g not in self._fcsa:
@@ -963,6 +991,12 @@ class GroupedPipeline(DevicePipeline):
         n = g * self.V
         self.ctx.set_stream(st.cuda_stream)
         with torch.cuda.stream(st):
+            order_ptr = None
+            if self.permute and not self.dev_skip_fits:
+                # the group's previous launch is over (collect() ran before the buffer was taken again): its order buffers are free
+                grp.h_order[:n] = self._dispatch_order(g)
+                self.ctx.memcpy_h2d_async(grp.order_dev.data_ptr(), grp._h_order_addr, n * 4)
+                order_ptr = grp.order_dev.data_ptr()
             if events is not None and len(events) > 5:
                 events[4].record(st)
             if not self.dev_skip_fits:
@@ -972,7 +1006,7 @@ class GroupedPipeline(DevicePipeline):
                                                   v['nfev'].data_ptr(), v['best'].data_ptr(), v['S2'].data_ptr(), v['C'].data_ptr(),
                                                   v['tau'].data_ptr(), v['chi'].data_ptr(), v['K'].data_ptr(),
                                                   work_ptr=grp.fitwork.data_ptr(),
-                                                  dispatch_order_ptr=self._dispatch_order(g).data_ptr() if self.permute else None,
+                                                  dispatch_order_ptr=order_ptr,
                                                   tail_signal=grp.signal, tail_value=grp.epoch + 1 if grp.signal else 0)
             if events is not None and len(events) > 5:
                 events[5].record(st)
@@ -1046,6 +1080,10 @@ class GroupedPipeline(DevicePipeline):
             self.nfev_last = {nP: r['nfev'][i][tried[i]] for i, nP in enumerate(self.listDoG)}
             if on_finished is not None:
                 on_finished(bv)
+        if res:                                # the cost prediction of the following launches: evaluations per residue, last batch
+            r = res[-1]
+            self._cost = np.where(r['status'] != -100, r['nfev'], 0).sum(axis=0).astype(np.int64)
+            self._cost_version += 1
         return res
 
     def run(self, vecs, nb, events=None, on_finished=None, on_enqueued=None, on_part=None):

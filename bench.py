@@ -161,6 +161,7 @@ def parse():
     ap.add_argument('--dispatch', type=str, default='history', choices=['history', 'random'],
                     help='grouped schedule, order of the merged launch\'s residues: history = longest first by the evaluation counts of the last collected batch (a prediction; exact here because the benchmark repeats one shard -- the random-order figure is reported beside the headline), random = fixed pseudo-random order')
     ap.add_argument('--depth', type=int, default=5, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
+    ap.add_argument('--no-h2d-stream', action='store_true', help='skip the upload-inclusive figure (value_with_h2d: every step\'s shard from pinned host memory)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cli-wall', action='store_true', help='skip the wall-clock run of the drop-in CLI chain (run-all.bash Step 3 + Step 4) on the same workload')
     ap.add_argument('--no-kernel-profile', action='store_true', help='skip the per-kernel alone / saturated timings after the timed region (the `kernels` entries then only carry in-pipeline durations)')
@@ -308,6 +309,62 @@ def cli_wall(vecs_host, s, cfg, cpu):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out
+
+
+class PinnedFeed:
+    """Feed of spinrelax_amd.pipeline.GroupedPipeline in which EVERY batch's shard arrives from page-locked host memory: the product's
+    resident-vector path (ResidentVectors.append_pinned = sr_vectors_append_f32, csrc/sr_vectors.hip) on a copy stream, two device
+    buffers -- batch k + 1 is in flight over PCIe while the kernels of batch k run.  The reference's unit of work starts at a
+    trajectory on the host (calculate-Ct-from-traj.py:458-470); this is that stream's rate."""
+
+    class _Src:
+        def __init__(self, ptr, shape):
+            self._ptr, self.shape = ptr, shape
+
+        def data_ptr(self):
+            return self._ptr
+
+    def __init__(self, torch, ctx, dev, host_addr, frames, V, nbuf=2):
+        self.torch, self.ctx, self.addr, self.frames, self.V, self.nbuf = torch, ctx, host_addr, frames, V, nbuf
+        self.copy = torch.cuda.Stream(device=dev)
+        self.rv = [ctx.vectors(V, capacity=frames) for _ in range(nbuf)]
+        self.free = [None] * nbuf
+        self.base = 0                    # batch number of the run's batch 0 (a run numbers its batches from 0)
+        self.issued = -1
+        self.last = -1
+
+    def begin(self, nb):
+        """a run of nb batches follows"""
+        self.base = self.issued + 1
+        self.last = self.base + nb - 1
+
+    def _issue(self, n):
+        b = n % self.nbuf
+        with self.torch.cuda.stream(self.copy):
+            if self.free[b] is not None:
+                self.copy.wait_event(self.free[b])           # the pack that read this buffer last has run
+            self.ctx.set_stream(self.copy.cuda_stream)
+            self.rv[b].truncate(0)
+            self.rv[b].append_pinned(self.addr, self.frames, self.V)
+        self.issued = n
+
+    def acquire(self, k, stream):
+        n = self.base + k
+        while self.issued < min(n + self.nbuf - 1, self.last):    # keep the copy engine one batch ahead
+            self._issue(self.issued + 1)
+        self.ctx.set_stream(stream.cuda_stream)
+        ptr = self.rv[n % self.nbuf].device_ptr()                # makes `stream` wait for the batch's frames
+        return PinnedFeed._Src(ptr, (self.frames, self.V, 3))
+
+    def release(self, k, stream):
+        ev = self.torch.cuda.Event()
+        ev.record(stream)
+        self.free[(self.base + k) % self.nbuf] = ev
+
+    def close(self):
+        for r in self.rv:
+            r.close()
+        self.rv = []
 
 
 def use_rfft_bench(args, s):
@@ -521,6 +578,29 @@ def main():
             t0 = time.perf_counter()
             run_batches(args.steady_steps)
             steady = (time.perf_counter() - t0) / args.steady_steps
+
+    # ---- the same K steps with every step's shard coming from page-locked HOST memory (upload-inclusive stream) ----
+    with_h2d = None
+    if grouped and not args.no_h2d_stream:
+        shard_bytes = int(vecs_host.nbytes)
+        haddr = ctx.host_alloc(shard_bytes)
+        import ctypes
+        hview = np.frombuffer((ctypes.c_char * shard_bytes).from_address(haddr), dtype=np.float32).reshape(vecs_host.shape)
+        np.copyto(hview, vecs_host)
+        feed = PinnedFeed(torch, ctx, dev, haddr, s['frames'], V)
+        with torch.cuda.stream(stream):
+            for timed_run in (False, True):
+                feed.begin(args.steps)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pipe.run(feed, args.steps, None, on_enqueued=gather_results, on_part=gather_part)
+                torch.cuda.synchronize()
+                if timed_run:
+                    with_h2d = (time.perf_counter() - t0) / args.steps
+        ctx.set_stream(stream.cuda_stream)
+        feed.close()
+        del hview
+        ctx.host_free(haddr)
 
     if world > 1:                  # every repeat: the slowest rank's time
         tmax = torch.tensor(samples + [steady or 0.0, random_dispatch or 0.0], device=dev, dtype=torch.float64)
@@ -860,6 +940,13 @@ def main():
             'ms_per_step': ms_per_step, 'timed_region_samples_ms_per_step': [x / args.steps * 1e3 for x in samples],
             'timed_region_note': 'the timed region (exactly %d steps between two synchronisations, fill and drain inside) was run %d times; '
                                  'value and ms_per_step are the median' % (args.steps, len(samples)),
+            'value_with_h2d': None if with_h2d is None else triples_total / with_h2d,
+            'with_h2d': None if with_h2d is None else {
+                'ms_per_step': with_h2d * 1e3, 'h2d_GBps': 12.0 * s['frames'] * V / with_h2d / 1e9, 'bytes_per_step': 12 * s['frames'] * V,
+                'note': 'the same %d steps (one warm-up run of the same length first) with every step\'s %.0f MB shard arriving from page-locked host memory: '
+                        'sr_vectors_append_f32 on a copy stream into two device buffers, batch k + 1 over PCIe while the kernels of batch k run '
+                        '(bench.py:PinnedFeed).  `value` (vectors resident in HBM) stays the headline; this is the rate of a stream that starts on the '
+                        'host, bound by the link (PCIe Gen5 x16: 63 GB/s spec)' % (args.steps, 12.0 * s['frames'] * V / 1e6)},
             'ms_per_step_random_dispatch': None if random_dispatch is None else random_dispatch * 1e3,
             'dispatch_note': 'the merged fit launch of a group takes its residues longest first by the evaluation counts of the last collected batch '
                              '(spinrelax_amd/pipeline.py:GroupedPipeline, dispatch = history): a prediction, exact in this benchmark because every step is the '

@@ -37,7 +37,7 @@ extern "C" {
 
 typedef struct sr_ctx sr_ctx;
 
-#define SR_ABI_VERSION 8
+#define SR_ABI_VERSION 9
 
 /* ---- context, memory, timing ------------------------------------------------------------- */
 int          sr_abi_version(void);
@@ -70,7 +70,11 @@ int          sr_stream_destroy(sr_ctx *, void *hip_stream);
 /* Signals: 32-bit values in memory that a KERNEL (or sr_stream_write_signal) sets and a stream waits for without the host
  * (hipStreamWaitValue32 on hipMallocSignalMemory).  sr_stream_wait_signal holds back everything queued afterwards on the
  * context's stream until *sig >= value; always pair a kernel-side release with an sr_stream_write_signal of the same value
- * behind that kernel, so that the wait ends at the latest when the kernel has finished.  NULL when the device cannot do it. */
+ * behind that kernel, so that the wait ends at the latest when the kernel has finished.  NULL when the device cannot do it.
+ * ORDERING RULE (enforced): the release must be SUBMITTED before the wait is queued -- first the releasing launch and its
+ * sr_stream_write_signal(sig, v) on their stream, then sr_stream_wait_signal(sig, v) on the waiting stream.  Streams of one
+ * priority share a few hardware queues; a wait queued ahead of its own release on a shared queue sits in front of it and never
+ * ends.  sr_stream_wait_signal returns -6 when no release of `value` (or more) has been submitted for the signal yet. */
 uint32_t    *sr_signal_alloc(sr_ctx *);
 int          sr_signal_free(sr_ctx *, uint32_t *sig);
 int          sr_stream_wait_signal(sr_ctx *, uint32_t *sig, uint32_t value);
@@ -180,7 +184,11 @@ int sr_rotate_vectors_perframe_f32(sr_ctx *, const float *vecs, int64_t N, int64
  *   sr_vectors_create        nV vectors, room for capacity_frames frames (grows when more are appended); NULL on failure
  *   sr_vectors_append_f32    n more frames from a HOST array (n, Vtot, 3): only the bytes of columns [v0, v0 + nV) cross
  *                            PCIe (row pitch 12 Vtot, width 12 nV), through two pinned staging buffers; synchronous with
- *                            respect to the host array, asynchronous on the device
+ *                            respect to the host array, asynchronous on the device.  A PAGE-LOCKED source (sr_host_alloc,
+ *                            hipHostMalloc / hipHostRegister) is read by the copy engine directly -- one asynchronous (2-D)
+ *                            copy, no staging pass; the caller then keeps it unchanged until the stream has passed the call
+ *   sr_vectors_frame_major_dev  device address of the (frames, nV, 3) array held (NULL on failure); work queued on the
+ *                            context's stream behind this call sees every appended frame (the feed of a device pipeline)
  *   sr_vectors_append_dev    n more frames from a DEVICE array (n, nV, 3) (e.g. an output of sr_xh_vectors_f32_dev)
  *   sr_vectors_append_xyz_f32  n more frames straight from HOST coordinates: obtain_XHvecs (+ centre / superpose) of
  *                            sr_xh_vectors_f32_dev for the bonds idxX[i] -> idxH[i], i < nV (the rank's slice of the
@@ -193,14 +201,16 @@ int sr_rotate_vectors_perframe_f32(sr_ctx *, const float *vecs, int64_t N, int64
  *   sr_vectors_hist_f32      kernel 0 (once per object) + kernel 2 over the first N_hist frames (<= 0: all): as
  *                            sr_rotate_hist_f32
  * Stream ordering: an append leaves its copies in flight on the context's current stream and records an event behind
- * them; every consumer (ct, ct_sums, hist, download) first makes ITS current stream wait for that event, so sr_set_stream
- * between an append and the next use loses no ordering.  chunk_start_host tables are range-checked against the frames held.
+ * them; every consumer (ct, ct_sums, hist, download, frame_major_dev) AND every further append first makes ITS current stream
+ * wait for that event, so sr_set_stream between an append and the next use or the next append loses no ordering (appends on
+ * different streams chain; the growth copy of a full object runs behind the frames it copies).  chunk_start_host tables are range-checked against the frames held.
  * sr_counter(ctx, "h2d_vector_bytes" | "vector_uploads"): bytes and calls of sr_vectors_append_f32 since sr_create (the
  * host-pointer entry points sr_ct_palmer_f32 / sr_rotate_hist_f32 go through it too). */
 typedef struct sr_vectors sr_vectors;
 sr_vectors *sr_vectors_create(sr_ctx *, int64_t nV, int64_t capacity_frames);
 void        sr_vectors_destroy(sr_ctx *, sr_vectors *);
 int64_t     sr_vectors_frames(const sr_vectors *);
+const float *sr_vectors_frame_major_dev(sr_ctx *, sr_vectors *);
 int sr_vectors_truncate(sr_ctx *, sr_vectors *, int64_t n_frames);
 int sr_vectors_append_f32(sr_ctx *, sr_vectors *, const float *vecs_host, int64_t n, int64_t Vtot, int64_t v0);
 int sr_vectors_append_dev(sr_ctx *, sr_vectors *, const float *vecs_dev, int64_t n);

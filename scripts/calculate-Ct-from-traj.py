@@ -86,7 +86,7 @@ def load_vector_files(files, default_dt):
                 v = z['vecs']
                 vl = z['vecs_lab'] if 'vecs_lab' in z else v
             names = list(z['names']) if 'names' in z else None
-            d = float(z['dt']) if 'dt' in z else default_dt
+            d = np.float32(z['dt']) if 'dt' in z else np.float32(default_dt)      # float32 like MDTraj's frame times (see load_mdtraj)
         if v.ndim != 3 or v.shape[2] != 3:
             print("= = = ERROR: vector file %s does not hold a (frames, bonds, 3) array!" % fn, file=sys.stderr)
             sys.exit(1)
@@ -149,7 +149,8 @@ def load_mdtraj(args, frames_per_chunk_of):
                 # a later chunk may hold a single frame (MDTraj's .timestep raises for it) and float32 frame times of
                 # later chunks give a time step that differs from the first one in its last bits
                 names = [trj.topology.atom(k).residue.resSeq for k in trj.topology.select(args.Hseltxt)]
-                d = float(trj.timestep)
+                d = trj.timestep          # MDTraj's np.float32, KEPT float32: the reference's int(tau/dt) and int(0.5*tau/dt)
+                                          # (:241, :255) are float32 divisions under NumPy >= 2 -- tau = 10, dt = 0.1 gives 100, not 99
                 iX, iH = select(trj)
                 if resXH is None:
                     resXH, dt, V = names, d, len(iX)

@@ -112,6 +112,7 @@ SIGNATURES = {
     'sr_vectors_create': (c_void_p, [c_void_p, c_int64, c_int64]),
     'sr_vectors_destroy': (None, [c_void_p, c_void_p]),
     'sr_vectors_frames': (c_int64, [c_void_p]),
+    'sr_vectors_frame_major_dev': (c_void_p, [c_void_p, c_void_p]),
     'sr_vectors_truncate': (c_int, [c_void_p, c_void_p, c_int64]),
     'sr_vectors_append_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64]),
     'sr_vectors_append_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
@@ -132,7 +133,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 8
+ABI_VERSION = 9
 LIB_PATH = os.environ.get('SPINRELAX_HIP_LIB', LIB_PATH)      # alternative build of the same ABI
 
 

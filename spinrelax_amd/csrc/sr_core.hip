@@ -210,10 +210,41 @@ uint32_t *sr_signal_alloc(sr_ctx *ctx)
     return p;
 }
 
+// The ordering rule of signals, enforced: the RELEASE of a value must have been SUBMITTED (sr_stream_write_signal; a kernel-side
+// release is always paired with one behind its launch) before a wait for that value is queued.  Streams of one priority are
+// multiplexed onto a few hardware queues; a wait queued ahead of its own release on a shared queue sits in front of it and never
+// ends (seen in round 4: a test queued the wait first and hung the box until the time limit).  The library keeps, per signal,
+// the largest value whose release has been submitted and refuses a wait for more.
+static int g_sig_mu = 0;
+static uint32_t *g_sig_ptr[64];
+static uint32_t g_sig_submitted[64];
+static int g_sig_n = 0;
+static void sig_lock() { while (__atomic_exchange_n(&g_sig_mu, 1, __ATOMIC_ACQUIRE)) { } }
+static void sig_unlock() { __atomic_store_n(&g_sig_mu, 0, __ATOMIC_RELEASE); }
+static int sig_slot(uint32_t *sig, bool create)          // under the lock
+{
+    for (int i = 0; i < g_sig_n; ++i)
+        if (g_sig_ptr[i] == sig) return i;
+    if (!create || g_sig_n >= 64) return -1;
+    g_sig_ptr[g_sig_n] = sig;
+    g_sig_submitted[g_sig_n] = 0u;
+    return g_sig_n++;
+}
+
 int sr_signal_free(sr_ctx *ctx, uint32_t *sig)
 {
     SR_CHECK_CTX(ctx);
-    if (sig) SR_HIP(hipFree(sig));
+    if (sig) {
+        sig_lock();
+        const int i = sig_slot(sig, false);
+        if (i >= 0) {
+            g_sig_ptr[i] = g_sig_ptr[g_sig_n - 1];
+            g_sig_submitted[i] = g_sig_submitted[g_sig_n - 1];
+            --g_sig_n;
+        }
+        sig_unlock();
+        SR_HIP(hipFree(sig));
+    }
     return 0;
 }
 
@@ -221,6 +252,14 @@ int sr_stream_wait_signal(sr_ctx *ctx, uint32_t *sig, uint32_t value)
 {
     SR_CHECK_CTX(ctx);
     SR_REQUIRE(sig != nullptr, -2, "sr_stream_wait_signal: NULL signal");
+    sig_lock();
+    const int i = sig_slot(sig, false);
+    const uint32_t have = i >= 0 ? g_sig_submitted[i] : 0u;
+    sig_unlock();
+    SR_REQUIRE(value == 0u || have >= value, -6,
+               "sr_stream_wait_signal: no release of value %u has been submitted for this signal (largest submitted: %u). Submit the "
+               "releasing launch and its sr_stream_write_signal BEFORE the wait: a wait queued first can share a hardware queue with "
+               "its own release and never end", value, have);
     SR_HIP(hipStreamWaitValue32(ctx->stream, sig, value, hipStreamWaitValueGte, 0xFFFFFFFFu));
     return 0;
 }
@@ -230,6 +269,11 @@ int sr_stream_write_signal(sr_ctx *ctx, uint32_t *sig, uint32_t value)
     SR_CHECK_CTX(ctx);
     SR_REQUIRE(sig != nullptr, -2, "sr_stream_write_signal: NULL signal");
     SR_HIP(hipStreamWriteValue32(ctx->stream, sig, value, 0));
+    sig_lock();
+    const int i = sig_slot(sig, true);
+    if (i >= 0 && value > g_sig_submitted[i]) g_sig_submitted[i] = value;
+    sig_unlock();
+    SR_REQUIRE(i >= 0, -4, "sr_stream_write_signal: more than 64 live signals");
     return 0;
 }
 

@@ -138,6 +138,14 @@ void sr_vectors_destroy(sr_ctx *ctx, sr_vectors *h)
 
 int64_t sr_vectors_frames(const sr_vectors *h) { return h ? h->N : -1; }
 
+const float *sr_vectors_frame_major_dev(sr_ctx *ctx, sr_vectors *h)
+{
+    if (!ctx || !h) { sr_set_error("sr_vectors_frame_major_dev: null pointer"); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { sr_set_error("hipSetDevice failed"); return nullptr; }
+    if (wait_ready(ctx, h) != 0) return nullptr;        // readers queued on ctx->stream behind this call see every appended frame
+    return h->fm;
+}
+
 int sr_vectors_truncate(sr_ctx *ctx, sr_vectors *h, int64_t n_frames)
 {
     SR_CHECK_CTX(ctx);
@@ -153,10 +161,32 @@ int sr_vectors_append_f32(sr_ctx *ctx, sr_vectors *h, const float *vecs, int64_t
     SR_REQUIRE(h && vecs, -2, "sr_vectors_append_f32: null pointer");
     SR_REQUIRE(n >= 1 && Vtot >= 1 && v0 >= 0 && v0 + h->nV <= Vtot, -3,
                "sr_vectors_append_f32: bad shape n=%lld Vtot=%lld v0=%lld nV=%lld", (long long)n, (long long)Vtot, (long long)v0, (long long)h->nV);
+    // chain behind whatever touched the object last, on whichever stream: an append on stream B after one on stream A (the single
+    // `ready` event is re-recorded below) and the growth copy of reserve() both see the earlier frames complete
+    if (int rc = wait_ready(ctx, h)) return rc;
     if (int rc = reserve(ctx, h, h->N + n)) return rc;
-    if (int rc = ensure_staging(ctx)) return rc;
     const size_t row = (size_t)h->nV * 3 * sizeof(float);                 // bytes of this rank's columns in one frame
     const size_t pitch = (size_t)Vtot * 3 * sizeof(float);
+    {
+        // page-locked source (sr_host_alloc, hipHostMalloc, hipHostRegister): the DMA engine reads it directly -- one (2-D when the
+        // rank owns a column range) asynchronous copy, no pass through the staging buffers.  The caller keeps the source alive
+        // and unchanged until the stream has passed this point (as with any asynchronous copy).
+        hipPointerAttribute_t at;
+        memset(&at, 0, sizeof(at));
+        if (hipPointerGetAttributes(&at, vecs) == hipSuccess && at.type == hipMemoryTypeHost) {
+            const char *src = reinterpret_cast<const char *>(vecs) + (size_t)v0 * 3 * sizeof(float);
+            char *dst = reinterpret_cast<char *>(h->fm) + (size_t)h->N * row;
+            if (row == pitch) SR_HIP(hipMemcpyAsync(dst, src, (size_t)n * row, hipMemcpyHostToDevice, ctx->stream));
+            else SR_HIP(hipMemcpy2DAsync(dst, row, src, pitch, row, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+            ctx->h2d_bytes += (unsigned long long)n * row;
+            ctx->h2d_calls += 1;
+            h->N += n;
+            h->packed = 0;
+            return mark_ready(ctx, h);
+        }
+        (void)hipGetLastError();                        // pageable memory: the attribute query reports an error, not a type
+    }
+    if (int rc = ensure_staging(ctx)) return rc;
     SR_REQUIRE(row <= kStageBytes, -3, "sr_vectors_append_f32: %lld vectors per frame exceed the staging buffer", (long long)h->nV);
     const int64_t rows_per_buf = (int64_t)(kStageBytes / row);
     const char *src = reinterpret_cast<const char *>(vecs) + (size_t)v0 * 3 * sizeof(float);
@@ -190,6 +220,7 @@ int sr_vectors_append_dev(sr_ctx *ctx, sr_vectors *h, const float *vecs_dev, int
     SR_CHECK_CTX(ctx);
     SR_REQUIRE(h && vecs_dev, -2, "sr_vectors_append_dev: null pointer");
     SR_REQUIRE(n >= 1, -3, "sr_vectors_append_dev: bad frame count %lld", (long long)n);
+    if (int rc = wait_ready(ctx, h)) return rc;
     if (int rc = reserve(ctx, h, h->N + n)) return rc;
     const size_t row = (size_t)h->nV * 3 * sizeof(float);
     SR_HIP(hipMemcpyAsync(reinterpret_cast<char *>(h->fm) + (size_t)h->N * row, vecs_dev, (size_t)n * row, hipMemcpyDeviceToDevice,

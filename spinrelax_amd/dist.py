@@ -31,8 +31,23 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        dist.init_process_group(backend=backend)
+        init_group(backend)
     return rank, world
+
+
+def init_group(backend):
+    """init_process_group with this rank BOUND to its GPU when the backend is RCCL ("nccl"): the current device is set and the
+    communicator is created for that device (`device_id`), so that no collective -- the barrier of finish() included -- has to
+    guess the device from the rank (torch's fallback is rank modulo device count, wrong as soon as LOCAL_RANK / SPINRELAX_DEVICE
+    say otherwise)."""
+    import torch
+    import torch.distributed as dist
+    if backend == 'nccl':
+        dev = local_device()
+        torch.cuda.set_device(dev)
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', dev))
+    else:
+        dist.init_process_group(backend=backend)
 
 
 def gather_vector_axis(local, V, axis, device=None):
@@ -110,7 +125,10 @@ def finish():
         shutil.rmtree(_SCRATCH.pop(), ignore_errors=True)
     d = _dist_or_none()
     if d is not None:
-        d.barrier()
+        if d.get_backend() == 'nccl':
+            d.barrier(device_ids=[local_device()])
+        else:
+            d.barrier()
         d.destroy_process_group()
 
 

@@ -572,6 +572,21 @@ class ResidentVectors:
     def truncate(self, n_frames):
         check(self.ctx.lib.sr_vectors_truncate(self.ctx.h, self.h, int(n_frames)), 'sr_vectors_truncate')
 
+    def append_pinned(self, host_addr, n, Vtot, v0=0):
+        """n more frames from PAGE-LOCKED host memory at `host_addr` ((n, Vtot, 3) float32): one asynchronous copy on the
+        context's current stream, no staging pass; the memory must stay unchanged until the stream has passed this point"""
+        check(self.ctx.lib.sr_vectors_append_f32(self.ctx.h, self.h, ctypes.c_void_p(int(host_addr)), int(n), int(Vtot), int(v0)),
+              'sr_vectors_append_f32')
+        return self
+
+    def device_ptr(self):
+        """device address of the (frames, nV, 3) float32 array; work queued on the context's stream behind this call sees
+        every appended frame"""
+        p = self.ctx.lib.sr_vectors_frame_major_dev(self.ctx.h, self.h)
+        if not p:
+            raise SpinRelaxHipError('sr_vectors_frame_major_dev failed: %s' % _lib.last_error())
+        return int(p)
+
     def download(self, f0=0, n=None):
         n = self.frames - f0 if n is None else n
         out = np.empty((n, self.nV, 3), dtype=np.float32)

@@ -899,6 +899,19 @@ class GroupedPipeline(DevicePipeline):
             self._fcsa[g] = self._relax_dev[2].repeat(1, g).contiguous() if self._relax_dev[2].dim() == 2 else self._relax_dev[2].repeat(g).contiguous()
         return self._fcsa[g]
 
+    def _pack_from(self, vecs, kk, buf):
+        """pack batch kk's vectors into plane buffer `buf` on the auxiliary stream.  `vecs`: a device tensor (frames, Vtot, 3), or a
+        FEED -- an object with acquire(kk, stream) -> object with data_ptr() / shape of that batch's device array (the feed makes
+        `stream` wait until the frames are there) and release(kk, stream) (called once the pack has been queued: the feed may
+        refill the buffer when `stream` has passed that point).  bench.py's PinnedFeed streams every batch from host memory."""
+        if hasattr(vecs, 'acquire'):
+            src = vecs.acquire(kk, self.aux)
+            self.ctx.set_stream(self.aux.cuda_stream)          # the feed drives the context from its own stream
+            self.stage_pack(src, buf)
+            vecs.release(kk, self.aux)
+        else:
+            self.stage_pack(vecs, buf)
+
     def _front_grouped(self, vecs, kk, grp, j, events, pack_next):
         bv = grp.batches[j]
         b = kk % self.NB
@@ -912,7 +925,7 @@ class GroupedPipeline(DevicePipeline):
                     self.aux.wait_event(self._ct_done_ev[b])
                 if self._hist_done_ev[b] is not None:
                     self.aux.wait_event(self._hist_done_ev[b])
-                self.stage_pack(vecs, buf)
+                self._pack_from(vecs, kk, buf)
                 self._packed_ev[b] = torch.cuda.Event()
                 self._packed_ev[b].record(self.aux)
         self._packed = False
@@ -960,7 +973,7 @@ class GroupedPipeline(DevicePipeline):
                     self.aux.wait_event(self._ct_done_ev[nb])
                 if self._hist_done_ev[nb] is not None:
                     self.aux.wait_event(self._hist_done_ev[nb])
-                self.stage_pack(pack_next, self.soa_bufs[nb])
+                self._pack_from(pack_next, kk + 1, self.soa_bufs[nb])
                 self._packed_ev[nb] = torch.cuda.Event()
                 self._packed_ev[nb].record(self.aux)
                 self._packed = True

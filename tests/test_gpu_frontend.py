@@ -167,8 +167,8 @@ def test_script_from_raw_coordinates_to_Ct(ctx, tmp_path):
     assert np.max(np.abs(np.array(Cx).T / Cl - 1)) < 1e-6
 
 
-@pytest.mark.parametrize('dt_ps', [10.0, float(np.float32(0.1))])
-def test_mdtraj_loader_streams_chunks_into_resident_vectors(tmp_path, dt_ps):
+@pytest.mark.parametrize('dt_ps,tau_ps', [(10.0, 1005.0), (float(np.float32(0.1)), 100.5 * float(np.float32(0.1))), (float(np.float32(0.1)), 10.0)])
+def test_mdtraj_loader_streams_chunks_into_resident_vectors(tmp_path, dt_ps, tau_ps):
     """load_mdtraj of the drop-in script EXECUTED (with tests/fake_mdtraj standing in for the absent MDTraj: it reads files
     and resolves selections, nothing else): two trajectory files read in --split chunks of 128 frames, every chunk's
     coordinates turned into bond vectors + superposition on the GPU and appended to the rank's resident vectors, each
@@ -176,11 +176,14 @@ def test_mdtraj_loader_streams_chunks_into_resident_vectors(tmp_path, dt_ps):
     the same coordinates given as .npz arrays (the whole-array path).
     The first file holds 4 * 128 + 1 frames -- its last chunk is ONE frame, for which MDTraj's .timestep raises -- and the
     second case has a 0.1 ps time step, whose float32 frame times give every chunk a time step that differs in its last
-    bits: the time step is a property of a file's first chunk only (reference :436-438), compared between files."""
+    bits: the time step is a property of a file's first chunk only (reference :436-438), compared between files.
+    Third case: tau an exact multiple of a 0.1 ps step.  MDTraj's time step is np.float32 and the reference divides by it as
+    it is (:241, :255): under NumPy >= 2 that is a float32 division, int(10 / np.float32(0.1)) = 100 frames per chunk, where the
+    same division in float64 gives 99 -- the script must keep the reference's arithmetic."""
     s = dict(synth.config_shapes(1))
-    s['dt'], s['tau_memory'] = dt_ps, 100.5 * dt_ps
-    F = int(s['tau_memory'] / s['dt'])
-    assert F == 100
+    s['dt'], s['tau_memory'] = dt_ps, tau_ps
+    F = int(s['tau_memory'] / np.float32(s['dt']))
+    assert F == 100 and (tau_ps != 10.0 or int(tau_ps / float(np.float32(dt_ps))) == 99)
     n1, n2 = 4 * 128 + 1, 3 * F + 63                                   # 13 and 63 frames of tail to drop
     d1 = synth.synth_coordinates(n1, 12, 31)
     d2 = synth.synth_coordinates(n2, 12, 32)
@@ -291,3 +294,43 @@ def test_round2_entry_points_refuse_bad_arguments(ctx):
         ctx.rscsa_search(**dict(ok, target=np.ones((2, 4))))
     with pytest.raises(ValueError):
         ctx.rscsa_search(**dict(ok, stats=np.ones((2, 3, 11))))
+
+
+def test_resident_vector_appends_on_different_streams_chain(ctx):
+    """sr_vectors_append_* on stream A, then on stream B, the consumer on stream C (sr_set_stream in between): every append first
+    waits for whatever touched the object last, so the second append's frames land behind the first one's, a growth copy of the
+    full object runs behind the frames it copies, and the consumer sees all of them.  Page-locked sources take the direct copy
+    (no staging pass) and must give the same object."""
+    import ctypes
+    import torch
+    F, V = 256, 24
+    a, b, c = (synth.synth_vectors(n, V, seed=sd) for n, sd in ((3 * F, 61), (2 * F, 62), (F, 63)))
+    whole = np.ascontiguousarray(np.concatenate([a, b, c]))
+    want = ctx.ct_palmer(whole, 6, F)
+    sA, sB, sC = (torch.cuda.Stream() for _ in range(3))
+    big = torch.zeros((4096, 4096), device='cuda')
+    rv = ctx.vectors(V, capacity=3 * F)                     # the third append has to grow the object
+    with torch.cuda.stream(sA):
+        for _ in range(4):
+            big = big @ big                                 # stream A is busy: its copies start late
+    ctx.set_stream(sA.cuda_stream)
+    rv.append(a)
+    ctx.set_stream(sB.cuda_stream)
+    rv.append(b)
+    # a page-locked source: the direct asynchronous copy
+    nbytes = c.nbytes
+    addr = ctx.host_alloc(nbytes)
+    pin = np.frombuffer((ctypes.c_char * nbytes).from_address(addr), dtype=np.float32).reshape(c.shape)
+    np.copyto(pin, c)
+    ctx.set_stream(sA.cuda_stream)
+    rv.append_pinned(addr, c.shape[0], V)
+    assert rv.frames == 6 * F
+    ctx.set_stream(sC.cuda_stream)
+    got = rv.ct(6, F)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(rv.download(0, 6 * F), whole)
+    ctx.set_stream(0)
+    torch.cuda.synchronize()
+    del pin
+    ctx.host_free(addr)
+    rv.close()

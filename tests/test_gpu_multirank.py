@@ -115,3 +115,17 @@ def test_more_ranks_than_vectors_shards_the_replicate_chunks(tmp_path, synth_cac
         else:
             assert filecmp.cmp(os.path.join(outs[1], f), os.path.join(outs[4], f), shallow=False), f
     assert open(os.path.join(outs[1], 'rotdif_Ctext.dat')).read() != open(os.path.join(outs[1], 'rotdif_Ctint.dat')).read()
+
+
+def test_rccl_world_size_one_beside_a_live_pipeline():
+    """The first RCCL initialisation of the product path must not happen on the 8-GPU node: backend "nccl" through
+    spinrelax_amd.dist.init_group (device bound with torch.cuda.set_device + device_id), a world of ONE rank, in the same
+    process as a live Context + GroupedPipeline; an all-gather of every group's table queued behind its last launch
+    (bench.py's consumer), the product's finish() (barrier with device_ids, destroy).  tests/rccl_world1_worker.py."""
+    PORT[0] += 1
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(PORT[0]),
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('SPINRELAX_DIST_BACKEND', None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'rccl_world1_worker.py')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=600, env=env)
+    assert p.returncode == 0 and b'RCCL_WORLD1_OK' in p.stdout, p.stdout.decode()[-3000:]

@@ -228,30 +228,38 @@ def test_batched_order_search_entry_point(setup):
 def test_signals_release_a_waiting_stream(setup):
     """sr_signal_alloc / sr_stream_write_signal / sr_stream_wait_signal: work queued behind a wait runs once the value is there
     (written by another stream here; by the merged fit launch's last workgroup in GroupedPipeline), a value already reached does
-    not block, NULL signals are refused."""
+    not block, NULL signals are refused -- and so is a wait whose release has not been submitted yet (the ordering rule)."""
     from spinrelax_amd.hip import SpinRelaxHipError
     st = setup
     torch, ctx, dev = st['torch'], st['ctx'], st['dev']
     sig = ctx.signal_alloc()
-    # the writer on a HIGH-priority stream: streams of one priority are multiplexed onto a few hardware queues (4 by default,
-    # assigned by use count), and a wait queued AHEAD of the write that releases it on the same hardware queue never ends.
-    # (The pipeline itself always submits the releasing launch before the wait.)  Priorities have queues of their own.
     a, b = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev)
     x = torch.zeros(1 << 20, device=dev)
+    big = torch.zeros((8192, 8192), device=dev)
     torch.cuda.synchronize()
+    # the ordering rule of the ABI: a wait for a value nobody has submitted a release for is REFUSED (queued ahead of its own
+    # release on a shared hardware queue it would never end -- round 4's hang)
+    ctx.set_stream(b.cuda_stream)
+    with pytest.raises(SpinRelaxHipError):
+        ctx.stream_wait_signal(sig, 1)
+    # the release is submitted first, behind ~20 ms of work on its (high-priority: own hardware queue) stream ...
+    ctx.set_stream(a.cuda_stream)
+    with torch.cuda.stream(a):
+        for _ in range(8):
+            big = big @ big
+    ctx.stream_write_signal(sig, 1)
+    # ... then the wait: what is queued behind it is parked until the value is there
     ctx.set_stream(b.cuda_stream)
     ctx.stream_wait_signal(sig, 1)
     with torch.cuda.stream(b):
         x.add_(1.0)
         done = torch.cuda.Event()
         done.record(b)
-    import time
-    time.sleep(0.05)
-    assert not done.query()                      # parked on the signal
-    ctx.set_stream(a.cuda_stream)
-    ctx.stream_write_signal(sig, 1)
+    assert not done.query()                      # parked on the signal: the writer is still behind its matrix products
     done.synchronize()
     assert float(x.sum().item()) == float(1 << 20)
+    with pytest.raises(SpinRelaxHipError):
+        ctx.stream_wait_signal(sig, 2)           # no release of 2 submitted
     ctx.set_stream(b.cuda_stream)
     ctx.stream_wait_signal(sig, 1)               # already reached (>=): passes
     with torch.cuda.stream(b):

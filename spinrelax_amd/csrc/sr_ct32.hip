@@ -342,7 +342,11 @@ __host__ __device__ constexpr int f32_img_slots(int N1) { return 256 * N1 + 256 
 // One half-length transform: the thread's N1 inputs v[] (natural order, element tid + 256 n1) -> for the 16 N1 threads
 // (k1, k2a) = (tid >> 4, tid & 15), k1 < N1: w[p] = X[k1 + N1 (k2a + 16 rev4(p))].  The caller has made sure nobody still
 // reads the LDS image; on return every thread has read what it needs from it (row tid is the thread's own).
-template <int N1>
+// SPECTRUM: the forward transforms of the loop -- the half of the row a partner thread reads (frequencies k2b >= 8: the partner
+// of (k, k2b' < 8) sits at 15 - k2b'; thread 0 pairs k2b' with 16 - k2b': 9 .. 15 and the pad slot, where it leaves Z[0]) goes
+// back to the thread's own row in frequency order, INSIDE the block that computed it: behind the block all 16 values would be live
+// at once across a branch merge (10 registers over the budget of four waves per SIMD, spilled and reloaded every pass).
+template <int N1, bool SPECTRUM>
 __device__ __forceinline__ void rfft32_workgroup(c32 *v, c32 *w, c32 *lds, const c32 *tw1, int tid
 #ifdef SR_CT32_STAMPS
                                                  , long long *stamp_acc, long long &stamp_t
@@ -398,6 +402,13 @@ __device__ __forceinline__ void rfft32_workgroup(c32 *v, c32 *w, c32 *lds, const
 #endif
         fftf_reg<4>(w);
         SR_STAMP(5)
+        if (SPECTRUM) {
+            c32 *bo = lds + 17 * tid;
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+                if (bitrevf<4>(p) >= 8) bo[bitrevf<4>(p)] = w[p];
+            if (tid == 0) bo[16] = w[0];
+        }
     }
 }
 
@@ -450,14 +461,17 @@ SR_PK c32 f32_sig5(c32 x, c32 y, c32 z, float m) { return pk_fma(z, z, pk_fma(x,
 #ifndef SR_CT32_PF
 #define SR_CT32_PF 0
 #endif
+#ifndef SR_CT32_WAVES16
+#define SR_CT32_WAVES16 2        // the same for the N1 = 16 kernel (M = 8192: 16 input blocks, twice the samples in flight): 193 VGPRs,
+                                 // no scratch (3: 168 VGPRs + 148 B of scratch, 3-6 % slower)
+#endif
 #ifndef SR_CT32_WAVES
-#define SR_CT32_WAVES 3          // waves per SIMD the N1 = 12 kernel is compiled for: 156 VGPRs, no scratch (4: 128 VGPRs and 72 B of
-                                 // scratch reloaded inside the transform loop -- 0.64 against 0.55 ms)
+#define SR_CT32_WAVES 4          // waves per SIMD the N1 = 12 kernel is compiled for: 124 VGPRs, no scratch, four workgroups per CU
 #endif
 // FULL: the chunk fills the loaded input blocks exactly (F = 512 NZ) and frames 2m, 2m + 1 share an aligned 8 bytes: no
 // frame masks, 8-byte loads only (cfg3 / cfg4: F = 4096 with N1 = 12).
 template <int N1, bool FULL>
-__global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft32(Ct32Args a)
+__global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : SR_CT32_WAVES16)) void k_ct_rfft32(Ct32Args a)
 {
     extern __shared__ __align__(16) unsigned char f32_smem[];
     c32 *lds = reinterpret_cast<c32 *>(f32_smem);
@@ -465,7 +479,9 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft
     constexpr int NZ = N1 == 12 ? 8 : 16;                          // input blocks that can hold frames (N1 = 12: F <= 4096)
     constexpr int IPT = N1 == 12 ? 8 : 11;                         // scan: half-series elements per thread (256 IPT >= ceil(F/2))
     c32 *tw1 = lds + f32_img_slots(N1) + 256;                      // 4 x 256 step-1 twiddle bases: w_H^(j tid), j = 1, 2, 4, 8
-    float *aux = reinterpret_cast<float *>(tw1 + 1024);            // [0 .. 32): wave partial sums; [32 .. 49): m_c, w_c m_c, weight of eps
+    c32 *tw3 = tw1 + 1024;                                         // 256 x w_M^t: the spectrum step's twiddle of thread (k1, k2a) at k1 + N1 k2a
+    float *aux = reinterpret_cast<float *>(tw3 + 256);             // [0 .. 32): wave partial sums; [32 .. 49): m_c, w_c m_c, weight of eps;
+                                                                   // [50]: P[H/2] (thread 0's self-paired frequency); [52 .. 54): K (double)
     const int tid0 = threadIdx.x;
     const int v = blockIdx.x / a.R, r = blockIdx.x - v * a.R;
     const int F = FULL ? 512 * NZ : a.F, L = FULL ? 256 * NZ : a.L;      // FULL: compile-time (most of the back transform's
@@ -473,8 +489,6 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft
     const int64_t start = a.chunk_start ? a.chunk_start[r] : (int64_t)r * F;
     const float *px = a.soa + ((int64_t)v * 3 + 0) * a.Npad + start;
     const bool even = FULL || ((start | a.Npad | (int64_t)F) & 1) == 0;   // frames 2m, 2m + 1 of every plane share an aligned 8 bytes
-    const c32 wbase = {a.tab->w3[2 * ((tid0 >> 4) < N1 ? (tid0 >> 4) + N1 * (tid0 & 15) : 0)],
-                       a.tab->w3[2 * ((tid0 >> 4) < N1 ? (tid0 >> 4) + N1 * (tid0 & 15) : 0) + 1]};   // w_M^(k1 + N1 k2a)
 
     // buffer resources that cover exactly the chunk's F frames of a plane: a frame past the chunk reads as 0
 #define SR_F32_LOAD1(DST, PLANE, T)                                                              \
@@ -503,13 +517,14 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft
         lds[f32_img_slots(N1) + tid0] = c32{a.tab->w2[2 * j], a.tab->w2[2 * j + 1]};
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) tw1[256 * jj + tid0] = c32{a.tab->w1[jj][2 * tid0], a.tab->w1[jj][2 * tid0 + 1]};
+        tw3[tid0] = c32{a.tab->w3[2 * tid0], a.tab->w3[2 * tid0 + 1]};
+        if (tid0 == 0) aux[50] = 0.f;
     }
 
     c32 sig[N1];                  // input of the next transform (entries >= NZ stay zero)
 #pragma unroll
     for (int n1 = 0; n1 < N1; ++n1) sig[n1] = c32{0.f, 0.f};
     int nsig;
-    double Kc;                    // 6 x (sum_c w_c m_c^2 (+ 1/3 for unit vectors))
     {
         // ---- prologue: chunk means of the signals, eps = |u|^2 - 1, signal 0 ----
         c32 xr[NZ], yr[NZ], zr[NZ];
@@ -554,7 +569,7 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft
         nsig = unit ? 5 : 6;
         // weights x 6 (1/6, 1/2, 2, 2, 2 and 1/3 for the trace): exact in float32; the lag sums are divided by 6 at the end
         const float wgt[6] = {1.0f, 3.0f, 12.0f, 12.0f, 12.0f, 2.0f};
-        Kc = unit ? 2.0 : 0.0;
+        double Kc = unit ? 2.0 : 0.0;          // 6 x (sum_c w_c m_c^2 (+ 1/3 for unit vectors)); kept in LDS until the epilogue
 #pragma unroll
         for (int c = 0; c < 6; ++c)
             if (c < 5 || !unit) Kc = fma((double)wgt[c] * (double)m[c], (double)m[c], Kc);
@@ -565,6 +580,7 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft
                 aux[40 + c] = wgt[c] * m[c];
             }
             aux[48] = unit ? 2.0f : 0.f;                       // 6 / 3: the weight of eps in e[j]
+            *reinterpret_cast<double *>(aux + 52) = Kc;
         }
 #pragma unroll
         for (int n1 = 0; n1 < NZ; ++n1) {
@@ -575,7 +591,6 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft
     }
     // power spectrum by pairs of frequencies (k, H - k), see k_ct_rfft: W2[q] = (P[k], P[H - k]) for the thread's k with k2b = q
     c32 W2[8];
-    float Wmid = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) W2[q] = c32{0.f, 0.f};
 #ifdef SR_CT32_STAMPS
@@ -602,16 +617,9 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft
             SR_F32_LOAD1(br, f32_plane_b(cn), tid)
         }
         c32 w[16];
-        rfft32_workgroup<N1>(sig, w, lds, tw1, tid SR_STAMP_ARGS);
-        // own row again, now in frequency order k2b; then every thread reads the partner frequencies of its 8 pairs.  Thread 0
-        // pairs k2b with 16 - k2b and k = 0 with "k = H", which is Z[0] again: it leaves Z[0] in the pad slot behind its row,
-        // where its partner column 16 - 0 points, and the general formula gives P[0] and P[H] (w_M^0 = 1).
-        if (act) {
-            c32 *b = lds + 17 * tid;
-#pragma unroll
-            for (int p = 0; p < 16; ++p) b[bitrevf<4>(p)] = w[p];
-            if (off0) b[16] = w[0];
-        }
+        rfft32_workgroup<N1, true>(sig, w, lds, tw1, tid SR_STAMP_ARGS);
+        // (the transform has left the partner-visible half of the thread's row in frequency order; thread 0 pairs k = 0 with "k = H",
+        // which is Z[0] again, read from the pad slot behind its row: the general formula then gives P[0] and P[H], w_M^0 = 1)
         SR_STAMP(6)
         if (SR_CT32_PF == 2 && cn < nsig) {
             SR_F32_LOAD1(ar, f32_plane_a(cn), tid)
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft
         if (act) {
             const float wgt = c == 0 ? 0.25f : (c == 1 ? 0.75f : (c == 5 ? 0.5f : 3.0f));    // 6 x weight / 4
             const c32 *b = lds + 17 * pt + off0;
-            const c32 wb = opaquef(wbase);
+            const c32 wb = tw3[k1 + N1 * k2a];
             // S = Z[k] + conj Z[H-k], D = Z[k] - conj Z[H-k], T = w_M^k D:  4 |A[k]|^2 = |S - i T|^2, 4 |A[H-k]|^2 = |S + i T|^2
 #pragma unroll
             for (int q = 0; q < 8; q += 2) {
@@ -639,7 +647,7 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft
                 const c32 D = {0.0f, 2.0f * zk.y};
                 const c32 T = cmulf(D, mulf_w32_rt(wb, 8));
                 const float pr = 2.0f * zk.x + T.y, pi = -T.x;
-                Wmid = fmaf(wgt, fmaf(pr, pr, pi * pi), Wmid);
+                aux[50] = fmaf(wgt, fmaf(pr, pr, pi * pi), aux[50]);
             }
         }
         SR_STAMP(8)
@@ -689,7 +697,7 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft
     if (act) {
         c32 *bk = lds + k1 + (N1 + 1) * k2a;                                    // own frequencies, column k2b = q
         c32 *bm = lds + (pt >> 4) + (N1 + 1) * (pt & 15) + 16 * (N1 + 1) * off0;  // the partner's, column 15 - q (+ 1 for thread 0)
-        const c32 wb = opaquef(wbase);
+        const c32 wb = tw3[k1 + N1 * k2a];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float E = W2[q].x + W2[q].y, d = W2[q].x - W2[q].y;
@@ -697,7 +705,7 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft
             bk[16 * (N1 + 1) * q] = c32{fmaf(d, wk.y, E), d * wk.x};
             if (!(q == 0 && off0)) bm[16 * (N1 + 1) * (15 - q)] = c32{fmaf(-d, wk.y, E), d * wk.x};
         }
-        if (off0) bk[16 * (N1 + 1) * 8] = c32{2.0f * Wmid, 0.0f};                // k = H/2: E = 2 P, d = 0
+        if (off0) bk[16 * (N1 + 1) * 8] = c32{2.0f * aux[50], 0.0f};             // k = H/2: E = 2 P, d = 0
     }
     __syncthreads();
     c32 w[16];
@@ -709,7 +717,7 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft
             yin[n1] = lds[k + k / N1];
         }
         __syncthreads();
-        rfft32_workgroup<N1>(yin, w, lds, tw1, tid SR_STAMP_ARGS);
+        rfft32_workgroup<N1, false>(yin, w, lds, tw1, tid SR_STAMP_ARGS);
     }
     __syncthreads();                                     // every read of the image is done: it now serves the scan
 
@@ -778,6 +786,7 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft
 #pragma unroll
         for (int w2 = 0; w2 < 3; ++w2) off += w2 < wave ? tot[w2] : 0.0;
         const double G0 = (tot[0] + tot[1]) + (tot[2] + tot[3]);
+        const double Kc = *reinterpret_cast<const double *>(aux + 52);
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
             const int d = i0 + k;
@@ -812,8 +821,8 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : 3)) void k_ct_rfft
 template <int N1>
 constexpr size_t f32_lds_bytes()
 {
-    // transform image + the 16 x 16 step-2 twiddles + the 4 x 256 step-1 bases + reduction scratch
-    return (size_t)(f32_img_slots(N1) + 256 + 1024) * sizeof(c32) + 64 * sizeof(float);
+    // transform image + the 16 x 16 step-2 twiddles + the 4 x 256 step-1 bases + the 256 spectrum twiddles + reduction scratch
+    return (size_t)(f32_img_slots(N1) + 256 + 1024 + 256) * sizeof(c32) + 64 * sizeof(float);
 }
 
 template <int N1, bool FULL>

@@ -828,6 +828,12 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
     }
     status = -99;
     nfev = 0;
+#ifdef SR_FIT_DEV_NJEV          // development: Jacobians evaluated (accepted steps + 1), returned in the high half of nfev
+    int njev = 0;
+#define SR_NJEV_INC() (++njev)
+#else
+#define SR_NJEV_INC()
+#endif
     double cost = INFINITY;
     double *A = T.matA(), *B = T.matB();     // LDS, workgroup-uniform
     double g[N];
@@ -846,6 +852,7 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
         } else {
             have_fit = true;
             eval_jac<N>(T, x, lb, ub, P.jac_mode, A, g, pcache);
+            SR_NJEV_INC();
             const int max_nfev = P.max_nfev > 0 ? P.max_nfev : 100 * N;
             double v[N], dv[N];
             // CL_scaling_vector
@@ -959,11 +966,16 @@ __device__ __forceinline__ void trf_solve(const R &T, const double *p0, const So
                     for (int i = 0; i < N; ++i) x[i] = uni(xn[i]);
                     cost = cost_new;
                     eval_jac<N>(T, x, lb, ub, P.jac_mode, A, g, pcache);
+                    SR_NJEV_INC();
                 }
             }
             status = term_set ? term : 0;
         }
     }
+#ifdef SR_FIT_DEV_NJEV
+    nfev |= njev << 16;
+#endif
+#undef SR_NJEV_INC
 
     // ---- outputs: popt, pcov = (J^T J)^-1 * 2 cost / (m - n)  (curve_fit, _minpack_py.py:1040-1055), chi ----
     cov_ok = false;

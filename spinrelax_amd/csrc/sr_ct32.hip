@@ -462,8 +462,7 @@ SR_PK c32 f32_sig5(c32 x, c32 y, c32 z, float m) { return pk_fma(z, z, pk_fma(x,
 #define SR_CT32_PF 0
 #endif
 #ifndef SR_CT32_WAVES16
-#define SR_CT32_WAVES16 2        // the same for the N1 = 16 kernel (M = 8192: 16 input blocks, twice the samples in flight): 193 VGPRs,
-                                 // no scratch (3: 168 VGPRs + 148 B of scratch, 3-6 % slower)
+#define SR_CT32_WAVES16 3        // the same for the N1 = 16 kernel (M = 8192: 16 input blocks): 146 VGPRs, no scratch, three workgroups per CU
 #endif
 #ifndef SR_CT32_WAVES
 #define SR_CT32_WAVES 4          // waves per SIMD the N1 = 12 kernel is compiled for: 124 VGPRs, no scratch, four workgroups per CU
@@ -491,15 +490,16 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : SR_CT32_WAVES16)) 
     const bool even = FULL || ((start | a.Npad | (int64_t)F) & 1) == 0;   // frames 2m, 2m + 1 of every plane share an aligned 8 bytes
 
     // buffer resources that cover exactly the chunk's F frames of a plane: a frame past the chunk reads as 0
-#define SR_F32_LOAD1(DST, PLANE, T)                                                              \
+#define SR_F32_LOAD1(DST, PLANE, T) SR_F32_LOADR(DST, PLANE, T, 0, NZ)
+#define SR_F32_LOADR(DST, PLANE, T, LO, HI)                                                      \
     {                                                                                            \
         const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                    \
             const_cast<float *>(px + (int64_t)__builtin_amdgcn_readfirstlane(PLANE) * a.Npad), (short)0, F * 4, 0x00020000); \
         if (even) {                                                                              \
-            _Pragma("unroll") for (int n1 = 0; n1 < NZ; ++n1)                                    \
+            _Pragma("unroll") for (int n1 = (LO); n1 < (HI); ++n1)                              \
                 DST[n1] = __builtin_bit_cast(c32, __builtin_amdgcn_raw_buffer_load_b64(rs_, 8 * ((T) + 256 * n1), 0, 0)); \
         } else {                                                                                 \
-            _Pragma("unroll") for (int n1 = 0; n1 < NZ; ++n1) {                                  \
+            _Pragma("unroll") for (int n1 = (LO); n1 < (HI); ++n1) {                            \
                 const int ob_ = 8 * ((T) + 256 * n1);                                            \
                 DST[n1] = c32{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, ob_, 0, 0)),               \
                               __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, ob_ + 4, 0, 0))};          \
@@ -654,28 +654,34 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : SR_CT32_WAVES16)) 
         // the next signal (w is dead here): d = a b - m_c
         if (cn < nsig) {
             asm volatile("" ::: "memory");
-            if (SR_CT32_PF == 0) {
-                SR_F32_LOAD1(ar, f32_plane_a(cn), tid)
-                SR_F32_LOAD1(br, f32_plane_b(cn), tid)
-            }
             const float mc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, aux[32 + cn])));
-            if (cn == 1) {                                         // x^2 - y^2
+            // the samples in groups of eight input blocks (NZ = 16: two groups, the second loaded behind the first one's signal --
+            // all sixteen at once are 64 registers on top of the signal's 32)
 #pragma unroll
-                for (int n1 = 0; n1 < NZ; ++n1) ar[n1] = f32_sig1(ar[n1], br[n1], mc);
-            } else if (cn == 5) {                                  // not unit vectors: |u|^2 (rare; the z load is exposed)
-                c32 zr[NZ];
-                SR_F32_LOAD1(zr, 2, tid)
+            for (int g0 = 0; g0 < NZ; g0 += 8) {
+                if (g0 > 0) asm volatile("" ::: "memory");
+                if (SR_CT32_PF == 0 || g0 > 0) {
+                    SR_F32_LOADR(ar, f32_plane_a(cn), tid, g0, g0 + 8)
+                    SR_F32_LOADR(br, f32_plane_b(cn), tid, g0, g0 + 8)
+                }
+                if (cn == 1) {                                     // x^2 - y^2
 #pragma unroll
-                for (int n1 = 0; n1 < NZ; ++n1) ar[n1] = f32_sig5(ar[n1], br[n1], zr[n1], mc);
-            } else {
+                    for (int n1 = g0; n1 < g0 + 8; ++n1) ar[n1] = f32_sig1(ar[n1], br[n1], mc);
+                } else if (cn == 5) {                              // not unit vectors: |u|^2 (rare; the z load is exposed)
+                    c32 zr[NZ];
+                    SR_F32_LOADR(zr, 2, tid, g0, g0 + 8)
 #pragma unroll
-                for (int n1 = 0; n1 < NZ; ++n1) ar[n1] = f32_sigp(ar[n1], br[n1], mc);
-            }
+                    for (int n1 = g0; n1 < g0 + 8; ++n1) ar[n1] = f32_sig5(ar[n1], br[n1], zr[n1], mc);
+                } else {
 #pragma unroll
-            for (int n1 = 0; n1 < NZ; ++n1) {
-                c32 d = ar[n1];
-                SR_F32_MASK(d.x, d.y, tid, n1)
-                sig[n1] = d;
+                    for (int n1 = g0; n1 < g0 + 8; ++n1) ar[n1] = f32_sigp(ar[n1], br[n1], mc);
+                }
+#pragma unroll
+                for (int n1 = g0; n1 < g0 + 8; ++n1) {
+                    c32 d = ar[n1];
+                    SR_F32_MASK(d.x, d.y, tid, n1)
+                    sig[n1] = d;
+                }
             }
 #pragma unroll
             for (int n1 = NZ; n1 < N1; ++n1) sig[n1] = c32{0.f, 0.f};
@@ -815,6 +821,7 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : SR_CT32_WAVES16)) 
     }
 #endif
 #undef SR_F32_LOAD1
+#undef SR_F32_LOADR
 #undef SR_F32_MASK
 }
 

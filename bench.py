@@ -122,7 +122,7 @@ def profile_staleness():
 
 def prof_entry(prof, prefix):
     for k, v in prof.items():
-        if k.startswith(prefix):
+        if k == prefix or k.startswith(prefix + '<'):
             return v
     return None
 
@@ -930,10 +930,13 @@ def main():
         roofline['fp64_issue_probe'] = probe
         roofline['frac_alone'] = tk.get('frac_alone')
         roofline['launches_of_this_kernel_in_flight'] = (tk.get('in_pipeline_ms') or 0.0) / ms_per_step if ms_per_step else None
-        roofline['chip'] = None if not (cfg == 3 and V == 512 and step_flop > 0) else {'fp64_flop_per_step': step_flop, 'TFLOPs': step_flop / (ms_per_step * 1e-3) / 1e12,
-                            'frac': step_flop / (ms_per_step * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
-                            'note': 'executed float64 flop of all kernels of a batch (committed PMC pass) over ms_per_step: the fraction of '
-                                    'the FP64 vector peak the pipeline as a whole sustains' + stale_txt, 'stale': stale}
+        step_flop32 = sum(float(v.get('fp32_flop_per_launch') or 0.0) for k, v in prof_all.items() if not k.startswith('k_fft_init') and not k.startswith('k_ct32_init'))
+        roofline['chip'] = None if not (cfg == 3 and V == 512 and step_flop > 0) else {
+            'fp64_flop_per_step': step_flop, 'fp32_flop_per_step': step_flop32,
+            'TFLOPs_fp64': step_flop / (ms_per_step * 1e-3) / 1e12, 'TFLOPs_fp32': step_flop32 / (ms_per_step * 1e-3) / 1e12,
+            'frac': (step_flop / PEAK_FP64_TFLOPS + step_flop32 / PEAK_FP32_TFLOPS) / 1e12 / (ms_per_step * 1e-3),
+            'note': 'executed float64 and float32 flop of all kernels of a batch (committed PMC pass) over ms_per_step, each against its vector '
+                    'peak: the share of the step during which the vector pipes would be busy at their peak rates' + stale_txt, 'stale': stale}
         res = {
             'metric': 'frame-vector-lag triples/s, C(t) + fit + R1/R2/NOE pipeline',
             'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -10,6 +10,9 @@ kernel trace, separate passes per counter set as MI355X_MICROARCH.md prescribes)
   stats, stats_alone        rocprofv3 --kernel-trace --stats: the driver's bench command / the same with --depth 1
   FETCH_SIZE, WRITE_SIZE    HBM traffic per kernel (--depth 1: the counters are device-wide)
   FP64                      SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64: executed float64 flop per launch
+  FP32                      SQ_INSTS_VALU_{ADD,MUL,FMA}_F32 (wave-instructions, a packed v_pk_* counted once) and
+                            SQ_INSTS_VALU_FLOPS_FP32 (operations per lane, a packed instruction counted twice, an FMA twice): executed
+                            float32 flop per launch = 64 x FLOPS_FP32
   RDREQ                     TCC_EA0_RDREQ / _32B: read requests by size (settles what FETCH_SIZE means for 8-byte loads)
   palmer_*                  the direct kernel k_ct_palmer alone (scripts/dev/ct_time.py with CT_FFT=0)
   cfg2_*                    BASELINE cfg2's size (bench.py --workload cfg2)
@@ -89,6 +92,19 @@ def hbm_json(raw, prefix, command):
                 w = {c: float(cnt[c].loc[k, 'mean']) for c in cnt}
                 out['kernels'][k]['fp64_wave_instructions'] = w
                 out['kernels'][k]['fp64_flop_per_launch'] = 64.0 * (w['ADD'] + w['MUL'] + 2.0 * w['FMA'] + w['TRANS'])
+    dfp = os.path.join(raw, prefix + 'FP32')
+    c32 = {c: counters(dfp, c) for c in ('SQ_INSTS_VALU_ADD_F32', 'SQ_INSTS_VALU_MUL_F32', 'SQ_INSTS_VALU_FMA_F32', 'SQ_INSTS_VALU_FLOPS_FP32')} \
+        if os.path.isdir(dfp) else {}
+    if c32 and all(v is not None for v in c32.values()):
+        out['fp32_note'] = ('fp32_flop_per_launch = 64 x SQ_INSTS_VALU_FLOPS_FP32 (the counter tallies float32 operations per lane: 2 for an FMA, '
+                            'twice that for a packed v_pk_*_f32; checked against ADD + MUL + 2 FMA wave-instructions: x 2 for a kernel whose '
+                            'float32 arithmetic is packed); fp32_wave_instructions: a packed instruction counted once')
+        for k in out['kernels']:
+            if all(k in c32[c].index for c in c32):
+                w = {c.replace('SQ_INSTS_VALU_', ''): float(c32[c].loc[k, 'mean']) for c in c32}
+                if w['FLOPS_FP32'] > 0:
+                    out['kernels'][k]['fp32_wave_instructions'] = {c: w[c] for c in ('ADD_F32', 'MUL_F32', 'FMA_F32')}
+                    out['kernels'][k]['fp32_flop_per_launch'] = 64.0 * w['FLOPS_FP32']
     return out
 
 
@@ -97,7 +113,7 @@ def issue_json(raw, build_id):
     quad-cycles summed over the waves / SIMDs that counted them (MI355X_MICROARCH.md, cycle constants)."""
     out = {}
     names = {}
-    for p in ('ISSUE1', 'ISSUE2', 'ISSUE3'):
+    for p in ('ISSUE1', 'ISSUE2', 'ISSUE3', 'ISSUE4', 'ISSUE5', 'ISSUE6'):
         fs = glob.glob(os.path.join(raw, p, '**', '*counter_collection.csv'), recursive=True)
         if not fs:
             continue
@@ -135,12 +151,12 @@ def ceiling_file(tag, build_id, iss, hbm, alone):
     """profiles/<tag>_ct_rfft_issue.json: the counters of k_ct_rfft the round-3 review asked for under this name, with the kernel's
     distance from its issue-limited ceiling worked out from them (a float64 instruction holds a SIMD's vector pipe for 4 cycles,
     any other VALU instruction for 2; the two-wave ceiling is the probe's, profiles/r*_fp64_issue_rate.txt)."""
-    key = next((k for k in iss['kernels'] if k.startswith('k_ct_rfft')), None)
+    key = next((k for k in iss['kernels'] if k.startswith('k_ct_rfft<')), None)
     if key is None or hbm is None or alone is None:
         return
     v = iss['kernels'][key]
     h = hbm['kernels'].get(key, {})
-    row = alone[alone.Name.str.contains('k_ct_rfft')]
+    row = alone[alone.Name.str.contains('k_ct_rfft<', regex=False)]
     if row.empty or 'fp64_flop_per_launch' not in h:
         return
     dur_us = float(row.AverageNs.iloc[0]) / 1e3
@@ -176,11 +192,46 @@ def ceiling_file(tag, build_id, iss, hbm, alone):
         # the other VALU instructions take half a float64 slot each
         d['frac_of_two_wave_ceiling'] = (fp64 + 0.5 * (valu - fp64)) / simds / dur_us / probe[2]
         d['fp64_only_frac_of_two_wave_ceiling'] = d['fp64_instr_per_us_per_simd'] / probe[2]
-    d['verdict'] = ('below the 85 % the review set as the bar for "only an instruction diet is left": the rest is wave-lifetime parked at '
-                    's_waitcnt / s_barrier and LDS-queue stalls with two waves per SIMD (DESIGN.md section 4, "Where its time goes")')
+    f2 = d.get('frac_of_two_wave_ceiling')
+    if f2 is not None:
+        d['verdict'] = ('%.0f %% of what two waves per SIMD can issue: %s the 85 %% the round-3 review set as the bar for "only an instruction diet is left"'
+                        % (100.0 * f2, 'below' if f2 < 0.85 else 'at or above'))
     with open(os.path.join(PROF, '%s_ct_rfft_issue.json' % tag), 'w') as fp:
         json.dump(d, fp, indent=1)
     print('ct_rfft issue:', {k: (round(x, 3) if isinstance(x, float) else x) for k, x in d.items() if k.startswith('frac') or k.startswith('fp64_')})
+
+
+def ct32_file(tag, build_id, iss, hbm, alone):
+    """profiles/<tag>_ct_rfft32_issue.json: where the float32 C(t) kernel stands -- executed float32 flop (PMC) over its duration alone
+    against the FP32 vector peak, the split of its waves' lifetime, how busy the vector pipe and the LDS are, the occupancy it reaches.
+    A packed instruction holds a SIMD's vector pipe for about 3.5 cycles, a plain one for 2 (profiles/r05_pk_issue_rate.txt)."""
+    key = next((k for k in iss['kernels'] if k.startswith('k_ct_rfft32')), None)
+    if key is None or hbm is None or alone is None:
+        return
+    v, h = iss['kernels'][key], hbm['kernels'].get(key, {})
+    row = alone[alone.Name.str.contains('k_ct_rfft32')]
+    if row.empty or 'fp32_flop_per_launch' not in h:
+        return
+    dur_us = float(row.AverageNs.iloc[0]) / 1e3
+    pk = float(sum(h['fp32_wave_instructions'].values()))
+    valu = v['SQ_INSTS_VALU']
+    clk = v['GRBM_GUI_ACTIVE'] / 8.0 / dur_us / 1e3 if v.get('GRBM_GUI_ACTIVE') else None
+    cyc = v['GRBM_GUI_ACTIVE'] / 8.0 if v.get('GRBM_GUI_ACTIVE') else None
+    d = {'build_id': build_id, 'kernel': key,
+         'command': 'scripts/profile_round.sh passes ISSUE1-6 + FP32 (rocprofv3 --pmc, bench.py --depth 1) and stats_alone; scripts/make_profiles.py',
+         'per_launch': {c: v[c] for c in sorted(v) if not c.endswith('_per_WAVE_CYCLES')},
+         'fp32_wave_instructions': h['fp32_wave_instructions'], 'fp32_flop_per_launch': h['fp32_flop_per_launch'],
+         'duration_alone_us': dur_us, 'clock_GHz_under_this_kernel': clk,
+         'TFLOPs_alone': h['fp32_flop_per_launch'] / dur_us / 1e6, 'frac_of_fp32_vector_peak': h['fp32_flop_per_launch'] / dur_us / 1e6 / 157.3,
+         'wave_lifetime': {c: v[c + '_per_WAVE_CYCLES'] for c in ('SQ_ACTIVE_INST_ANY', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY') if c + '_per_WAVE_CYCLES' in v}}
+    if cyc:
+        d['vector_pipe_busy'] = (3.5 * pk + 2.0 * (valu - pk)) / 1024.0 / cyc
+        if v.get('SQ_LDS_IDX_ACTIVE'):
+            d['lds_busy'] = v['SQ_LDS_IDX_ACTIVE'] / 256.0 / cyc
+            d['lds_bank_conflict_share'] = v.get('SQ_LDS_BANK_CONFLICT', 0.0) / v['SQ_LDS_IDX_ACTIVE']
+    with open(os.path.join(PROF, '%s_ct_rfft32_issue.json' % tag), 'w') as fp:
+        json.dump(d, fp, indent=1)
+    print('ct_rfft32:', {k: (round(x, 3) if isinstance(x, float) else x) for k, x in d.items() if k in ('TFLOPs_alone', 'frac_of_fp32_vector_peak', 'vector_pipe_busy', 'lds_busy', 'duration_alone_us')})
 
 
 def main():
@@ -217,11 +268,12 @@ def main():
     if iss is not None:
         with open(os.path.join(PROF, '%s_issue_counters.json' % tag), 'w') as fp:
             json.dump(iss, fp, indent=1)
-        for k in ('k_ct_rfft', 'k_order_search'):
+        for k in ('k_ct_rfft', 'k_order_search'):      # (k_ct_rfft32 included)
             for kk, v in iss['kernels'].items():
                 if kk.startswith(k):
                     print('issue', kk[:40], {c: round(x, 3) for c, x in v.items() if c.endswith('_per_WAVE_CYCLES') or c.startswith('VALU_busy')})
         ceiling_file(tag, build_id, iss, out, sa)
+        ct32_file(tag, build_id, iss, out, sa)
     # the direct kernel alone
     pal = {}
     for name, ctrs in (('palmer_FETCH', ['FETCH_SIZE']), ('palmer_WRITE', ['WRITE_SIZE']),

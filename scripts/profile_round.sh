@@ -29,6 +29,7 @@ echo "stats_alone done"
 #     be charged to each other
 for pass in "FETCH_SIZE:FETCH_SIZE" "WRITE_SIZE:WRITE_SIZE" \
             "FP64:SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" \
+            "FP32:SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_FLOPS_FP32" \
             "RDREQ:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
     name=${pass%%:*}; ctr=${pass#*:}
     timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$name -- \
@@ -39,7 +40,8 @@ done
 #      is, what the waves wait for, LDS activity -- the evidence behind "x % of the issue-limited ceiling" 
 for pass in "ISSUE1:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" \
             "ISSUE2:SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM" \
-            "ISSUE3:SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
+            "ISSUE3:SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" \
+            "ISSUE4:MeanOccupancyPerCU" "ISSUE5:LdsLatency" "ISSUE6:VmemLatency"; do
     name=${pass%%:*}; ctr=${pass#*:}
     timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$name -- \
         python3 $root/bench.py --steps 3 --warmup 1 --depth 1 $short > $out/$name.log 2>&1 || echo "pass $name FAILED"

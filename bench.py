@@ -161,6 +161,7 @@ def parse():
     ap.add_argument('--dispatch', type=str, default='history', choices=['history', 'random'],
                     help='grouped schedule, order of the merged launch\'s residues: history = longest first by the evaluation counts of the last collected batch (a prediction; exact here because the benchmark repeats one shard -- the random-order figure is reported beside the headline), random = fixed pseudo-random order')
     ap.add_argument('--depth', type=int, default=5, help='batches in flight: the straggler tail of the last fit order of batch k overlaps batches k+1 .. k+depth-1 (1 = strictly serial steps)')
+    ap.add_argument('--shard', type=str, default=None, help='r/N: time the vector range rank r of N would own under --scaling strong, alone on this GPU and without a process group (per-rank figures behind the scaling prediction of DESIGN.md section 7)')
     ap.add_argument('--no-h2d-stream', action='store_true', help='skip the upload-inclusive figure (value_with_h2d: every step\'s shard from pinned host memory)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cli-wall', action='store_true', help='skip the wall-clock run of the drop-in CLI chain (run-all.bash Step 3 + Step 4) on the same workload')
@@ -425,6 +426,10 @@ def main():
             sys.exit('bench.py: --scaling strong needs the %d vectors of the workload to divide by the %d ranks (equal all-gather pieces)' % (Vtot, world))
         from spinrelax_amd.dist import shard_range
         v0, V = shard_range(Vtot, rank, world)
+        if args.shard:
+            sr, sn = (int(x) for x in args.shard.split('/'))
+            v0, V = shard_range(Vtot, sr, sn)
+            Vtot = V                       # the figures of this run are the shard's own
     else:
         V = args.vectors or s['V']
         Vtot, v0 = V * world, rank * V

@@ -486,7 +486,11 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : SR_CT32_WAVES16)) 
     const int F = FULL ? 512 * NZ : a.F, L = FULL ? 256 * NZ : a.L;      // FULL: compile-time (most of the back transform's
                                                                          // outputs are lags beyond L, and fold away)
     const int64_t start = a.chunk_start ? a.chunk_start[r] : (int64_t)r * F;
+#ifdef SR_CT32_EXP_HOTLOADS     // timing experiment (wrong results): every series reads the first series' samples -- all loads hit the caches
+    const float *px = a.soa + (start & 1);
+#else
     const float *px = a.soa + ((int64_t)v * 3 + 0) * a.Npad + start;
+#endif
     const bool even = FULL || ((start | a.Npad | (int64_t)F) & 1) == 0;   // frames 2m, 2m + 1 of every plane share an aligned 8 bytes
 
     // buffer resources that cover exactly the chunk's F frames of a plane: a frame past the chunk reads as 0

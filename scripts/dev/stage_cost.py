@@ -15,6 +15,8 @@ s = synth.config_shapes(3)
 V = 512
 vecs_host = synth.synth_vectors_parallel(s['frames'], V, s['seed'])
 ctx = Context(0)
+if os.environ.get('CT_WG_PER_CU'):
+    ctx.set_option('ct_wg_per_cu', int(os.environ['CT_WG_PER_CU']))
 dev = torch.device('cuda', 0)
 vecs = torch.from_numpy(vecs_host).to(dev)
 pipe = GroupedPipeline(ctx, dev, s['frames'], V, s['R'], s['F'], s['dt'], group=32, q_rot=synth.Q_EXT, Diso=synth.DISO, aniso=synth.DANI,

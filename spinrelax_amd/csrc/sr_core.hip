@@ -143,6 +143,11 @@ int sr_set_option(sr_ctx *ctx, const char *name, int value)
         ctx->ct_fft = value;
         return 0;
     }
+    if (!strcmp(name, "ct_wg_per_cu")) {
+        SR_REQUIRE(value >= 0 && value <= 8, -3, "sr_set_option: ct_wg_per_cu must be 0 .. 8");
+        ctx->ct_wg_per_cu = value;
+        return 0;
+    }
     if (!strcmp(name, "ct_traceless")) {
         SR_REQUIRE(value == 0 || value == 1, -3, "sr_set_option: ct_traceless must be 0 or 1");
         ctx->ct_traceless = value;

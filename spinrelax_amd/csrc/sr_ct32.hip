@@ -839,8 +839,14 @@ constexpr size_t f32_lds_bytes()
 template <int N1, bool FULL>
 int launch_ct_rfft32_h(sr_ctx *ctx, const Ct32Args &a, int64_t series)
 {
-    const size_t lds = f32_lds_bytes<N1>();
+    size_t lds = f32_lds_bytes<N1>();
     static_assert(f32_lds_bytes<N1>() <= 64 * 1024, "k_ct_rfft32: the image is meant to fit the default LDS grant");
+    // option ct_wg_per_cu (0 = as many as fit): a larger LDS request caps the workgroups a CU holds, which leaves registers free on
+    // every SIMD for the waves of the bandwidth kernels that run beside this one in the pipeline (pack, histogram)
+    if (ctx->ct_wg_per_cu > 0) {
+        const size_t cap = ((size_t)160 * 1024 / (size_t)ctx->ct_wg_per_cu) & ~(size_t)1023;
+        if (cap > lds && cap <= 64 * 1024) lds = cap;
+    }
     // the scan's tables share the image: F floats, then L + 1 doubles
     static_assert((size_t)f32_img_slots(N1) * sizeof(c32) >= (N1 == 12 ? 4096 * 4 : 5464 * 4), "k_ct_rfft32: E does not fit the image");
     static_assert((size_t)f32_img_slots(N1) * sizeof(c32) >= (N1 == 12 ? 2049 * 8 : 2732 * 8), "k_ct_rfft32: Tt does not fit the image");

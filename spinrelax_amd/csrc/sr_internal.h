@@ -23,6 +23,7 @@ struct sr_ctx {
     int ct_fft;         // kernel 1 when the chunk length allows: 3 (default) = float32 real-input FFT (k_ct_rfft32) for 4096 < F + L <=
                         // 8192, the float64 complex FFT below; 2 = the float64 real-input FFT (k_ct_rfft) in that range;
                         // 1 = complex float64 FFT formulation (k_ct_fft) everywhere, 0 = always the direct kernel
+    int ct_wg_per_cu;   // k_ct_rfft32: at most this many workgroups per CU (0 = as many as fit: 4 for M = 6144); see sr_ct32.hip
     int ct_traceless;   // 1: k_ct_rfft<12> in its traceless five-signal form (faster alone, slower inside the pipeline: default 0)
     int fft_table_ready;
     int fft32_table_ready;

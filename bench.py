@@ -930,8 +930,11 @@ def main():
             compulsory = 12.0 * s['frames'] * V + 16.0 * L * V + 8.0 * V * 2592
             roofline['hbm_bytes_per_step'] = {'pmc': step_bytes, 'compulsory': compulsory, 'ratio': step_bytes / compulsory,
                                               'GBps': step_bytes / (ms_per_step * 1e-3) / 1e9,
-                                              'note': 'sum over the kernels of a batch of the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE) against '
-                                                      'vectors in once + C(t), dC(t), histogram out; not measured in this run%s' % stale_txt}
+                                              'note': 'sum over the kernels of a batch of the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE: requests the L2s send to the '
+                                                      'fabric, Infinity-Cache hits included) against vectors in once + C(t), dC(t), histogram out; not measured in this run. '
+                                                      'The pack writes the planes once and they are read by kernel 1 and kernel 2 (1.84 GB of it); k_ct_rfft32 re-reads its '
+                                                      'planes per pass and, at four workgroups per CU, 128 x 48 KB per XCD exceed its 4 MB L2: 1.7 GB of re-reads come from the '
+                                                      'Infinity Cache (DESIGN.md section 4)%s' % stale_txt}
         roofline['fp64_issue_probe'] = probe
         roofline['frac_alone'] = tk.get('frac_alone')
         roofline['launches_of_this_kernel_in_flight'] = (tk.get('in_pipeline_ms') or 0.0) / ms_per_step if ms_per_step else None

@@ -150,7 +150,7 @@ def parse():
     ap.add_argument('--fit-lds', type=int, default=-1, help='1/0: keep residue data in LDS during the fits (-1 = library default)')
     ap.add_argument('--dev-skip-fits', action='store_true', help='DEVELOPMENT ONLY (invalid as a benchmark): leave the fits and the relaxation kernel out, to see the floor the C(t) side alone sets')
     ap.add_argument('--hist-on-main', action='store_true', help='keep the histogram kernel in line with C(t) (only the pack runs beside it)')
-    ap.add_argument('--ct-fft', type=int, default=-1, help='kernel 1: 3 = float32 real-input FFT (k_ct_rfft32) where it applies, 2 = float64 real-input FFT (k_ct_rfft), 1 = complex float64 FFT (k_ct_fft), 0 = direct (k_ct_palmer); -1 = library default (3)')
+    ap.add_argument('--ct-fft', type=int, default=-1, help='kernel 1: 4 = float32 transforms for every 1024 < F + L <= 8192, 3 = float32 real-input FFT (k_ct_rfft32) for 4096 < F + L <= 8192, 2 = float64 real-input FFT (k_ct_rfft), 1 = complex float64 FFT (k_ct_fft), 0 = direct (k_ct_palmer); -1 = library default (3)')
     ap.add_argument('--ct-traceless', type=int, default=0, help='1: k_ct_rfft<12> with five transforms (traceless components; library option ct_traceless, default off)')
     ap.add_argument('--group', type=int, default=32, help='batches whose fits / relaxation run as ONE merged launch behind their C(t) kernels (GroupedPipeline; a run of K steps uses groups of min(K, group)); 1 = every batch launches its own fits (DevicePipeline, --depth of them in flight)')
     ap.add_argument('--pack-cus', type=int, default=128, help='grouped schedule: CUs the pack stream is confined to (0 = all; the compute streams always have the whole chip)')
@@ -373,7 +373,7 @@ def use_rfft_bench(args, s):
 
 
 def use_rfft32_bench(args, s):
-    return args.ct_fft in (-1, 3) and 4096 < s['F'] + s['L'] <= 8192
+    return (args.ct_fft in (-1, 3) and 4096 < s['F'] + s['L'] <= 8192) or (args.ct_fft == 4 and 1024 < s['F'] + s['L'] <= 8192)
 
 
 def fft32_exec_flop(s, V):
@@ -382,7 +382,7 @@ def fft32_exec_flop(s, V):
     real-signal spectrum step (24 flop per frequency) for five signals, and per frame the signals (about 14 flop) twice (prologue
     means, epilogue e[j])."""
     need = s['F'] + s['L']
-    M = 6144 if need <= 6144 else 8192
+    M = 2048 if need <= 2048 else (4096 if need <= 4096 else (6144 if need <= 6144 else 8192))
     H = M // 2
     return M, s['R'] * V * (6 * (5 * H * np.log2(H) + 12 * H) + 5 * 24 * H + 60 * s['F'])
 
@@ -706,18 +706,18 @@ def main():
         if 1024 < s['F'] + s['L'] <= 8192 and args.ct_fft != 0:
             ctx.set_option('ct_fft', 0)
             alone['ct_direct'] = timed(lambda: p1.stage_ct(s0, finalize=False), reps=2)
-            if args.ct_fft in (-1, 2, 3) and s['F'] + s['L'] > 4096:
+            if args.ct_fft in (-1, 2, 3, 4) and (s['F'] + s['L'] > 4096 or args.ct_fft == 4):
                 ctx.set_option('ct_fft', 1)                       # and the complex-FFT formulation it replaced, for reference
                 alone['ct_complex_fft'] = timed(lambda: p1.stage_ct(s0, finalize=False), reps=2)
                 if use_rfft32_bench(args, s):
-                    ctx.set_option('ct_fft', 2)                   # the float64 real-input transform kernel (rounds 2-4's production kernel)
+                    ctx.set_option('ct_fft', 2)                   # the float64 transform kernel of this chunk length (rounds 2-4's production kernel)
                     alone['ct_rfft_f64'] = timed(lambda: p1.stage_ct(s0, finalize=False), reps=2)
             ctx.set_option('ct_fft', 3 if args.ct_fft < 0 else args.ct_fft)
             with torch.cuda.stream(st1):
                 p1.stage_ct(s0)                 # restore the slot's sums / C(t) from the production kernel
         # the other real-input FFT variant (M = 8192: 4096 < F <= 5461) on the same planes, at two chunk lengths: its cost per
         # frame against the benchmark variant's
-        if use_rfft_bench(args, s):
+        if use_rfft_bench(args, s) and s['frames'] >= 5461:
             per_frame = alone['ct'] / (s['R'] * s['F'])
             for F2 in (5000, 5461):
                 R2 = s['frames'] // F2
@@ -761,7 +761,7 @@ def main():
         triples_total = synth.exact_triples(s['R'], s['F'], Vtot)
         value = triples_total / (elapsed / args.steps)
         use_fft = (args.ct_fft != 0) and 1024 < s['F'] + s['L'] <= 8192
-        use_rfft = use_fft and args.ct_fft in (-1, 2, 3) and s['F'] + s['L'] > 4096
+        use_rfft = use_fft and args.ct_fft in (-1, 2, 3, 4) and s['F'] + s['L'] > 4096
         use_f32 = use_fft and use_rfft32_bench(args, s)
         kname = 'k_ct_rfft32' if use_f32 else ('k_ct_rfft' if use_rfft else ('k_ct_fft' if use_fft else 'k_ct_palmer'))
         prof, prof_src = committed_profile() if cfg == 3 and V == 512 else ({}, None)

@@ -55,7 +55,8 @@ int          sr_sync(sr_ctx *);
  * 512-residue benchmark batch); results are bit-identical only between runs with the same value), "fit_lds" = 1/0 keep
  * a residue's t, C(t), 1/sigma in LDS, "ct_fft" = formulation of kernel 1 where the chunk length allows: 3 (default) the
  * FLOAT32 real-input FFT for 4096 < F + L <= 8192 (the reference's own arithmetic type; C(t) to 4e-8) and the float64 complex
- * FFT below, 2 the float64 real-input FFT in that range (C(t) to 1e-15), 1 the float64 complex FFT everywhere, 0 always direct;
+ * FFT below, 4 float32 transforms for every 1024 < F + L <= 8192, 2 the float64 real-input FFT for 4096 < F + L <= 8192 (C(t) to
+ * 1e-15), 1 the float64 complex FFT everywhere, 0 always direct;
  * "ct_traceless" = 1/0 (default 0): the real-input FFT kernel for F <= 4096 transforms the five traceless components of
  * u (x) u and takes the trace term from a scan of |u|^2 - 1 (one transform fewer; series that are not unit vectors fall back
  * to six inside the kernel) -- 4 % faster alone, 3 % slower per step inside the pipeline, same results to 1e-13. */

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Developer timing of the C(t) sums kernel alone on the cfg3 planes; CT_FFT=0/1/2 selects the formulation."""
+"""Developer timing of the C(t) sums kernel alone on the cfg3 planes (CFG=2: cfg2's, NVEC of them); CT_FFT=0..4 selects the
+formulation."""
 import os
 import sys
 
@@ -10,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from spinrelax_amd import synth                      # noqa: E402
 from spinrelax_amd.hip import Context                # noqa: E402
 
-s = synth.config_shapes(3)
+s = synth.config_shapes(int(os.environ.get('CFG', '3')))
 V = int(os.environ.get('NVEC', '512'))
 pre = synth.synth_vectors_parallel(s['frames'], V, s['seed'])
 ctx = Context(0)

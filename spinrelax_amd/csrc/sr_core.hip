@@ -139,7 +139,7 @@ int sr_set_option(sr_ctx *ctx, const char *name, int value)
         return 0;
     }
     if (!strcmp(name, "ct_fft")) {
-        SR_REQUIRE(value >= 0 && value <= 3, -3, "sr_set_option: ct_fft must be 0, 1, 2 or 3");
+        SR_REQUIRE(value >= 0 && value <= 4, -3, "sr_set_option: ct_fft must be 0 .. 4");
         ctx->ct_fft = value;
         return 0;
     }

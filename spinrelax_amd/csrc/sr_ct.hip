@@ -1553,7 +1553,7 @@ int sr_ct_palmer_sums_f32_dev(sr_ctx *ctx, const float *soa, int64_t Npad, int64
             SR_HIP(hipStreamSynchronize(ctx->stream));      // once per context: later launches may come on other streams
             ctx->fft_table_ready = 1;
         }
-        if (ctx->ct_fft == 3 && need > 4096)       // float32 transforms (sr_ct32.hip)
+        if (ctx->ct_fft == 4 || (ctx->ct_fft == 3 && need > 4096))       // float32 transforms (sr_ct32.hip)
             return sr_launch_ct_rfft32(ctx, soa, Npad, chunk_start_host, cs_dev, psum, (int)R, (int)F, (int)L, (int)Lp, series);
         if (ctx->ct_fft >= 2 && need > 4096) {
             // real-input formulation: half-length transforms, two workgroups per CU

@@ -1,5 +1,5 @@
 // sr_ct32.hip -- kernel 1 in the reference's own arithmetic type: the Wiener-Khinchin form of the Palmer-chunked P2
-// autocorrelation with FLOAT32 transforms (k_ct_rfft32), for 4096 < F + L <= 8192.
+// autocorrelation with FLOAT32 transforms (k_ct_rfft32): production for 4096 < F + L <= 8192, option for 1024 < F + L <= 4096.
 //
 // Reference semantics: calculate_Ct_Palmer, calculate-Ct-from-traj.py:200-238 -- which computes in float32
 // (`Ct = np.zeros(..., dtype=vecs.dtype)`, :219; the shifted products :222-228).  The float64 kernels of sr_ct.hip
@@ -211,9 +211,10 @@ __device__ __forceinline__ void fftf_reg(c32 *v)
 }
 
 template <int N1>
-struct FStage1 {                                           // N1 = 16
-    __host__ __device__ static constexpr int k1(int p) { return bitrevf<4>(p); }
-    __device__ static __forceinline__ void run(c32 *v) { fftf_reg<4>(v); }
+struct FStage1 {                                           // N1 = 4, 8, 16
+    static constexpr int LOG = N1 == 4 ? 2 : (N1 == 8 ? 3 : 4);
+    __host__ __device__ static constexpr int k1(int p) { return bitrevf<LOG>(p); }
+    __device__ static __forceinline__ void run(c32 *v) { fftf_reg<LOG>(v); }
 };
 template <int B>
 __device__ __forceinline__ void dft3f_col12(c32 *v, c32 (*y)[4])
@@ -269,8 +270,23 @@ __device__ __forceinline__ void applyf_twiddles(c32 *v, const c32 *tw, int tid)
     pw[2] = opaquef(tw[256 + tid]);
     pw[4] = opaquef(tw[512 + tid]);
     pw[8] = opaquef(tw[768 + tid]);
-    static_assert(N == 12 || N == 16, "two step-1 sizes");
+    static_assert(N == 4 || N == 8 || N == 12 || N == 16, "the step-1 sizes");
     static_assert(KOF::k1(0) == 0, "entry 0 carries no twiddle");
+    if constexpr (N == 4) {                                // k1(p) = 0, 2, 1, 3
+        pw[3] = cmulf(pw[1], pw[2]);
+        cmulf2(v[1], pw[2], v[2], pw[1]);
+        v[3] = cmulf(v[3], pw[3]);
+        return;
+    } else if constexpr (N == 8) {                         // k1(p) = 0, 4, 2, 6, 1, 5, 3, 7
+        pw[3] = pw[1]; pw[5] = pw[1];
+        cmulf2(pw[3], pw[2], pw[5], pw[4]);
+        pw[6] = pw[2]; pw[7] = pw[3];
+        cmulf2(pw[6], pw[4], pw[7], pw[4]);
+        v[1] = cmulf(v[1], pw[4]);
+#pragma unroll
+        for (int p = 2; p + 1 < N; p += 2) cmulf2(v[p], pw[KOF::k1(p)], v[p + 1], pw[KOF::k1(p + 1)]);
+        return;
+    }
     pw[3] = pw[1]; pw[5] = pw[1]; pw[6] = pw[2]; pw[9] = pw[1]; pw[10] = pw[2];
     cmulf2(pw[3], pw[2], pw[5], pw[4]);
     cmulf2(pw[6], pw[4], pw[9], pw[8]);
@@ -298,10 +314,11 @@ struct Ct32Tab {
     float w2[2 * 256];
     float w3[2 * 256];
 };
-__global__ void k_ct32_init_table(Ct32Tab *tab)          // tab[0]: N1 = 12, tab[1]: N1 = 16
+__host__ __device__ constexpr int f32_tab_set(int N1) { return N1 / 4 - 1; }       // N1 = 4, 8, 12, 16 -> 0 .. 3
+__global__ void k_ct32_init_table(Ct32Tab *tab)          // tab[N1 / 4 - 1], H = 256 N1
 {
     const int t = threadIdx.x, set = blockIdx.x;
-    const double H = set == 0 ? 3072.0 : 4096.0;
+    const double H = 1024.0 * (double)(set + 1);
     double sn, cs;
     for (int j = 0; j < 4; ++j) {
         const int e = (t << j) % (int)H;                   // exact argument reduction
@@ -470,13 +487,14 @@ SR_PK c32 f32_sig5(c32 x, c32 y, c32 z, float m) { return pk_fma(z, z, pk_fma(x,
 // FULL: the chunk fills the loaded input blocks exactly (F = 512 NZ) and frames 2m, 2m + 1 share an aligned 8 bytes: no
 // frame masks, 8-byte loads only (cfg3 / cfg4: F = 4096 with N1 = 12).
 template <int N1, bool FULL>
-__global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : SR_CT32_WAVES16)) void k_ct_rfft32(Ct32Args a)
+__global__ __launch_bounds__(256, (N1 == 16 ? SR_CT32_WAVES16 : SR_CT32_WAVES)) void k_ct_rfft32(Ct32Args a)
 {
     extern __shared__ __align__(16) unsigned char f32_smem[];
     c32 *lds = reinterpret_cast<c32 *>(f32_smem);
     constexpr int H = N1 * 256, M = 2 * H;
-    constexpr int NZ = N1 == 12 ? 8 : 16;                          // input blocks that can hold frames (N1 = 12: F <= 4096)
-    constexpr int IPT = N1 == 12 ? 8 : 11;                         // scan: half-series elements per thread (256 IPT >= ceil(F/2))
+    // input blocks (of 512 frames) that can hold frames: F + L <= M with L = F/2, i.e. F <= 1365 / 2730 / 4096 / 5461 for N1 = 4 / 8 / 12 / 16
+    constexpr int NZ = N1 == 4 ? 3 : (N1 == 8 ? 6 : (N1 == 12 ? 8 : 16));
+    constexpr int IPT = N1 == 4 ? 3 : (N1 == 8 ? 6 : (N1 == 12 ? 8 : 11));     // scan: half-series elements per thread (256 IPT >= ceil(F/2))
     c32 *tw1 = lds + f32_img_slots(N1) + 256;                      // 4 x 256 step-1 twiddle bases: w_H^(j tid), j = 1, 2, 4, 8
     c32 *tw3 = tw1 + 1024;                                         // 256 x w_M^t: the spectrum step's twiddle of thread (k1, k2a) at k1 + N1 k2a
     float *aux = reinterpret_cast<float *>(tw3 + 256);             // [0 .. 32): wave partial sums; [32 .. 49): m_c, w_c m_c, weight of eps;
@@ -663,25 +681,26 @@ __global__ __launch_bounds__(256, (N1 == 12 ? SR_CT32_WAVES : SR_CT32_WAVES16)) 
             // all sixteen at once are 64 registers on top of the signal's 32)
 #pragma unroll
             for (int g0 = 0; g0 < NZ; g0 += 8) {
+                constexpr int GE = 8 < NZ ? 8 : NZ;         // blocks per group
                 if (g0 > 0) asm volatile("" ::: "memory");
                 if (SR_CT32_PF == 0 || g0 > 0) {
-                    SR_F32_LOADR(ar, f32_plane_a(cn), tid, g0, g0 + 8)
-                    SR_F32_LOADR(br, f32_plane_b(cn), tid, g0, g0 + 8)
+                    SR_F32_LOADR(ar, f32_plane_a(cn), tid, g0, g0 + GE)
+                    SR_F32_LOADR(br, f32_plane_b(cn), tid, g0, g0 + GE)
                 }
                 if (cn == 1) {                                     // x^2 - y^2
 #pragma unroll
-                    for (int n1 = g0; n1 < g0 + 8; ++n1) ar[n1] = f32_sig1(ar[n1], br[n1], mc);
+                    for (int n1 = g0; n1 < g0 + GE; ++n1) ar[n1] = f32_sig1(ar[n1], br[n1], mc);
                 } else if (cn == 5) {                              // not unit vectors: |u|^2 (rare; the z load is exposed)
                     c32 zr[NZ];
-                    SR_F32_LOADR(zr, 2, tid, g0, g0 + 8)
+                    SR_F32_LOADR(zr, 2, tid, g0, g0 + GE)
 #pragma unroll
-                    for (int n1 = g0; n1 < g0 + 8; ++n1) ar[n1] = f32_sig5(ar[n1], br[n1], zr[n1], mc);
+                    for (int n1 = g0; n1 < g0 + GE; ++n1) ar[n1] = f32_sig5(ar[n1], br[n1], zr[n1], mc);
                 } else {
 #pragma unroll
-                    for (int n1 = g0; n1 < g0 + 8; ++n1) ar[n1] = f32_sigp(ar[n1], br[n1], mc);
+                    for (int n1 = g0; n1 < g0 + GE; ++n1) ar[n1] = f32_sigp(ar[n1], br[n1], mc);
                 }
 #pragma unroll
-                for (int n1 = g0; n1 < g0 + 8; ++n1) {
+                for (int n1 = g0; n1 < g0 + GE; ++n1) {
                     c32 d = ar[n1];
                     SR_F32_MASK(d.x, d.y, tid, n1)
                     sig[n1] = d;
@@ -848,8 +867,9 @@ int launch_ct_rfft32_h(sr_ctx *ctx, const Ct32Args &a, int64_t series)
         if (cap > lds && cap <= 64 * 1024) lds = cap;
     }
     // the scan's tables share the image: F floats, then L + 1 doubles
-    static_assert((size_t)f32_img_slots(N1) * sizeof(c32) >= (N1 == 12 ? 4096 * 4 : 5464 * 4), "k_ct_rfft32: E does not fit the image");
-    static_assert((size_t)f32_img_slots(N1) * sizeof(c32) >= (N1 == 12 ? 2049 * 8 : 2732 * 8), "k_ct_rfft32: Tt does not fit the image");
+    constexpr size_t Fmax = N1 == 4 ? 1365 : (N1 == 8 ? 2730 : (N1 == 12 ? 4096 : 5461));
+    static_assert((size_t)f32_img_slots(N1) * sizeof(c32) >= (Fmax + 3) * 4, "k_ct_rfft32: E does not fit the image");
+    static_assert((size_t)f32_img_slots(N1) * sizeof(c32) >= (Fmax / 2 + 2) * 8, "k_ct_rfft32: Tt does not fit the image");
     hipLaunchKernelGGL((k_ct_rfft32<N1, FULL>), dim3((unsigned)series), dim3(256), lds, ctx->stream, a);
     SR_HIP(hipGetLastError());
     return 0;
@@ -857,15 +877,18 @@ int launch_ct_rfft32_h(sr_ctx *ctx, const Ct32Args &a, int64_t series)
 
 }  // namespace
 
-// Called by sr_ct_palmer_sums_f32_dev (sr_ct.hip) when ct_fft = 3 and 4096 < F + L <= 8192.  chunk starts: cs_host (may be
+// Called by sr_ct_palmer_sums_f32_dev (sr_ct.hip): ct_fft = 3 (default) for 4096 < F + L <= 8192, ct_fft = 4 for every 1024 < F + L <= 8192.
+// (Why the shorter chunks keep float64 transforms by default: at cfg2's size the launch is 80 us either way, and the drop-in chain THROUGH
+// ITS TEXT FILES -- _Ctint.dat keeps 8 digits -- reproduces the reference's printed digits only with float64 C(t); with float32 C(t) one
+// of 16 cfg2 residues lands 1.1e-6 from the reference's through-files table, tests/test_gpu_cli.py.)  chunk starts: cs_host (may be
 // null: chunk r starts at r F) is what decides the aligned fast path, cs_dev is what the kernel reads.
 int sr_launch_ct_rfft32(sr_ctx *ctx, const float *soa, int64_t Npad, const int64_t *cs_host, const int64_t *cs_dev, double *psum,
                         int R, int F, int L, int Lp, int64_t series)
 {
-    Ct32Tab *tab = (Ct32Tab *)sr_workspace(ctx, SR_WS_FFT32, 2 * sizeof(Ct32Tab));
+    Ct32Tab *tab = (Ct32Tab *)sr_workspace(ctx, SR_WS_FFT32, 4 * sizeof(Ct32Tab));
     if (!tab) return -5;
     if (!ctx->fft32_table_ready) {
-        hipLaunchKernelGGL(k_ct32_init_table, dim3(2), dim3(256), 0, ctx->stream, tab);
+        hipLaunchKernelGGL(k_ct32_init_table, dim3(4), dim3(256), 0, ctx->stream, tab);
         SR_HIP(hipGetLastError());
         SR_HIP(hipStreamSynchronize(ctx->stream));      // once per context: later launches may come on other streams
         ctx->fft32_table_ready = 1;
@@ -876,12 +899,20 @@ int sr_launch_ct_rfft32(sr_ctx *ctx, const float *soa, int64_t Npad, const int64
     bool aligned = (Npad & 1) == 0 && (F & 1) == 0 && (((uintptr_t)soa) & 7) == 0;
     if (cs_host)
         for (int r = 0; r < R; ++r) aligned = aligned && (cs_host[r] & 1) == 0;
-    if (F + L <= 6144) {
-        SR_REQUIRE(F <= 4096, -3, "k_ct_rfft32<12>: F=%d does not fit 8 input blocks", F);
-        a.tab = tab;
+    const int need = F + L;
+    SR_REQUIRE(need > 1024 && need <= 8192, -3, "k_ct_rfft32: F=%d outside the transform lengths", F);
+    if (need <= 2048) {
+        a.tab = tab + f32_tab_set(4);
+        return launch_ct_rfft32_h<4, false>(ctx, a, series);
+    }
+    if (need <= 4096) {
+        a.tab = tab + f32_tab_set(8);
+        return launch_ct_rfft32_h<8, false>(ctx, a, series);
+    }
+    if (need <= 6144) {
+        a.tab = tab + f32_tab_set(12);
         return aligned && F == 4096 ? launch_ct_rfft32_h<12, true>(ctx, a, series) : launch_ct_rfft32_h<12, false>(ctx, a, series);
     }
-    SR_REQUIRE(F + L <= 8192, -3, "k_ct_rfft32<16>: F=%d too long", F);
-    a.tab = tab + 1;
+    a.tab = tab + f32_tab_set(16);
     return launch_ct_rfft32_h<16, false>(ctx, a, series);
 }

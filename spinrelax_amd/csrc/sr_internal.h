@@ -21,7 +21,8 @@ struct sr_ctx {
     int fit_waves;      // waves per residue in the model-order search: 1, 2 or 4
     int fit_lds;        // 1: stage t, y, 1/sigma of a residue in LDS when it fits; 0: read them from global memory
     int ct_fft;         // kernel 1 when the chunk length allows: 3 (default) = float32 real-input FFT (k_ct_rfft32) for 4096 < F + L <=
-                        // 8192, the float64 complex FFT below; 2 = the float64 real-input FFT (k_ct_rfft) in that range;
+                        // 8192, the float64 complex FFT below; 4 = float32 transforms for every 1024 < F + L <= 8192;
+                        // 2 = the float64 real-input FFT (k_ct_rfft) for 4096 < F + L <= 8192;
                         // 1 = complex float64 FFT formulation (k_ct_fft) everywhere, 0 = always the direct kernel
     int ct_wg_per_cu;   // k_ct_rfft32: at most this many workgroups per CU (0 = as many as fit: 4 for M = 6144); see sr_ct32.hip
     int ct_traceless;   // 1: k_ct_rfft<12> in its traceless five-signal form (faster alone, slower inside the pipeline: default 0)

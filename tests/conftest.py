@@ -92,12 +92,12 @@ def committed_tally(section, key, measured):
         raise
 
 
-def ct_f32_transform(F):
-    """True when the production dispatch of kernel 1 (ct_fft = 3) runs FLOAT32 transforms for this chunk length
-    (k_ct_rfft32, sr_ct32.hip): 4096 < F + L <= 8192.  Its bars: C(t) 1e-7 relative; the replicate means p_r it feeds into dC(t)
+def ct_f32_transform(F, ct_fft=3):
+    """True when kernel 1 runs FLOAT32 transforms for this chunk length (k_ct_rfft32, sr_ct32.hip): the production dispatch
+    (ct_fft = 3) for 4096 < F + L <= 8192, ct_fft = 4 for every 1024 < F + L <= 8192.  Its bars: C(t) 1e-7 relative; the replicate means p_r it feeds into dC(t)
     5e-8 absolute (measured 3e-8: the rounding of a float32 transform does not average down with the chunk length the way the
     direct kernel's per-product rounding does), i.e. |d dC(t)| <= 5e-8 / (sqrt(R) - 1)."""
-    return 4096 < F + F // 2 <= 8192
+    return (4096 if ct_fft == 3 else 1024) < F + F // 2 <= 8192 and ct_fft in (3, 4)
 
 
 def dct_close_f32_transform(dCt, ref, R, Ct=None):

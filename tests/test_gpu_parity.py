@@ -112,7 +112,7 @@ def test_ct_ragged_and_edge_sizes(ctx, liboracle, F, R, V):
             assert dct_close(dCt, dCr, R, F)
 
 
-@pytest.mark.parametrize('ct_fft', [3, 2])
+@pytest.mark.parametrize('ct_fft', [3, 4, 2])
 @pytest.mark.parametrize('F,R,V', [(683, 2, 3), (684, 2, 3), (1365, 3, 2), (1366, 2, 2), (2000, 2, 3), (2730, 2, 2), (2731, 2, 2),
                                    (3000, 2, 2), (4096, 2, 3), (4097, 2, 2), (5000, 2, 2), (5461, 2, 1), (5462, 2, 1)])
 def test_ct_fft_formulation_all_transform_sizes(ctx, liboracle, F, R, V, ct_fft):
@@ -120,7 +120,8 @@ def test_ct_fft_formulation_all_transform_sizes(ctx, liboracle, F, R, V, ct_fft)
     every switch: 2048 / 4096 / 8192 points, chunks that fill at most half of the transform (upper half skipped) and
     chunks that do not, the last length that fits (5461) and the first that falls back to the direct kernel (5462).
     Checked against the plain-C float64 oracle.  ct_fft = 2: float64 transforms everywhere, float64 accuracy.  ct_fft = 3 (the
-    default): FLOAT32 transforms for 4096 < F + L <= 8192 (k_ct_rfft32: F = 2731 .. 5461 here), within the float32 bars."""
+    default): FLOAT32 transforms for 4096 < F + L <= 8192 (k_ct_rfft32: F = 2731 .. 5461 here), within the float32 bars; ct_fft = 4:
+    float32 transforms at every transform length (M = 2048 and 4096 as well)."""
     vecs = synth.synth_vectors(R * F + 5, V, seed=300 + F)
     v4 = vecs[:R * F].reshape(R, F, V, 3)
     Cr, dCr = c_oracle_ct(liboracle, v4)
@@ -132,7 +133,7 @@ def test_ct_fft_formulation_all_transform_sizes(ctx, liboracle, F, R, V, ct_fft)
         ctx.set_option('ct_fft', 3)
     assert Ct.shape == (F // 2, V)
     uses_fft = 1024 < F + F // 2 <= 8192
-    if uses_fft and ct_fft == 3 and ct_f32_transform(F):
+    if uses_fft and ct_f32_transform(F, ct_fft):
         assert relerr(Ct, Cr) < 1e-7 and dct_close_f32_transform(dCt, dCr, R)
         assert relerr(Ct, Ct1) < 1e-7
     else:
@@ -142,14 +143,16 @@ def test_ct_fft_formulation_all_transform_sizes(ctx, liboracle, F, R, V, ct_fft)
 
 
 def test_ct_rfft32_float32_transforms(ctx, liboracle):
-    """k_ct_rfft32 (sr_ct32.hip), the production kernel of cfg3 / cfg4: float32 transforms of the mean-removed traceless
+    """k_ct_rfft32 (sr_ct32.hip), the production kernel of cfg3 / cfg4 (4096 < F + L <= 8192; shorter chunks with ct_fft = 4): float32 transforms of the mean-removed traceless
     components, mean terms restored in float64.  Against the plain-C float64 oracle on every path of the kernel: the aligned
     full-chunk form (F = 4096), masked chunks (F < 4096, odd F), the 8192-point transform, odd chunk starts (32-bit loads),
     series that are not unit vectors (the sixth signal |u|^2: scaled vectors, zero vectors of vecnorm_NDarray's 0/0 guard, one frame
     just outside the unit tolerance), constant vectors, and the series of one launch mixed.  Bars: C(t) 1e-7 relative (measured
     2-5e-8), dC(t) 5e-8 / (sqrt(R) - 1) absolute (conftest.dct_close_f32_transform)."""
     worst = 0.0
-    for F, R, V in ((4096, 3, 6), (4000, 3, 2), (3001, 3, 2), (2732, 4, 2), (4094, 2, 2), (4097, 3, 2), (5000, 3, 2), (5333, 2, 2), (5461, 2, 1)):
+    ctx.set_option('ct_fft', 4)            # float32 transforms at every length (the default takes them for 4096 < F + L <= 8192)
+    for F, R, V in ((4096, 3, 6), (4000, 3, 2), (3001, 3, 2), (2732, 4, 2), (4094, 2, 2), (4097, 3, 2), (5000, 3, 2), (5333, 2, 2), (5461, 2, 1),
+                    (684, 3, 6), (1000, 4, 2), (1365, 3, 2), (1366, 3, 6), (2001, 3, 2), (2730, 2, 2), (2731, 2, 2)):       # M = 2048, 4096 too
         vecs = synth.synth_vectors(R * F + 7, V, seed=500 + F).copy()
         if V >= 2:
             vecs[:, 1] *= np.float32(1.7)                               # not unit: whole series scaled
@@ -162,6 +165,7 @@ def test_ct_rfft32_float32_transforms(ctx, liboracle):
         e = relerr(Ct, Cr)
         worst = max(worst, e)
         assert e < 1e-7 and dct_close_f32_transform(dCt, dCr, R, Cr), (F, R, e, np.max(np.abs(dCt - dCr)))
+    ctx.set_option('ct_fft', 3)
     print('\n[k_ct_rfft32] worst C(t) relative error over the shapes: %.2e' % worst)
     # odd chunk starts (two "files" whose first one has an odd number of frames)
     F = 4096
@@ -212,7 +216,13 @@ def test_ct_multi_file_chunk_starts(ctx, liboracle):
     assert R == v4.shape[0] == 5
     Ct, dCt = ctx.ct_palmer(cat, R, F, chunk_start=starts)
     Cr, dCr = c_oracle_ct(liboracle, v4)
-    assert relerr(Ct, Cr) < 1e-12 and np.max(np.abs(dCt - dCr)) < 1e-12
+    assert relerr(Ct, Cr) < 1e-12 and np.max(np.abs(dCt - dCr)) < 1e-12              # float64 transforms at this length (the default)
+    ctx.set_option('ct_fft', 4)                                                     # float32 transforms
+    try:
+        Ct, dCt = ctx.ct_palmer(cat, R, F, chunk_start=starts)
+    finally:
+        ctx.set_option('ct_fft', 3)
+    assert relerr(Ct, Cr) < 1e-7 and dct_close_f32_transform(dCt, dCr, R)
 
 
 def test_ct_size_independent_properties(ctx):

@@ -151,11 +151,12 @@ def parse():
     ap.add_argument('--dev-skip-fits', action='store_true', help='DEVELOPMENT ONLY (invalid as a benchmark): leave the fits and the relaxation kernel out, to see the floor the C(t) side alone sets')
     ap.add_argument('--hist-on-main', action='store_true', help='keep the histogram kernel in line with C(t) (only the pack runs beside it)')
     ap.add_argument('--ct-fft', type=int, default=-1, help='kernel 1: 4 = float32 transforms for every 1024 < F + L <= 8192, 3 = float32 real-input FFT (k_ct_rfft32) for 4096 < F + L <= 8192, 2 = float64 real-input FFT (k_ct_rfft), 1 = complex float64 FFT (k_ct_fft), 0 = direct (k_ct_palmer); -1 = library default (3)')
+    ap.add_argument('--ct-wg-per-cu', type=int, default=0, help='DEVELOPMENT: cap of k_ct_rfft32 workgroups per CU (library option ct_wg_per_cu; 0 = as many as fit)')
     ap.add_argument('--ct-traceless', type=int, default=0, help='1: k_ct_rfft<12> with five transforms (traceless components; library option ct_traceless, default off)')
     ap.add_argument('--group', type=int, default=32, help='batches whose fits / relaxation run as ONE merged launch behind their C(t) kernels (GroupedPipeline; a run of K steps uses groups of min(K, group)); 1 = every batch launches its own fits (DevicePipeline, --depth of them in flight)')
     ap.add_argument('--pack-cus', type=int, default=128, help='grouped schedule: CUs the pack stream is confined to (0 = all; the compute streams always have the whole chip)')
     ap.add_argument('--psum-buffers', type=int, default=3, help='grouped schedule: raw-sum buffers the C(t) launches rotate through')
-    ap.add_argument('--late-hist', type=int, default=1, help='grouped schedule: 1 = the histograms of a group run in the tail of its merged fit launch (released by the signal the launch\'s last workgroup writes; the planes of group + 3 batches stay alive), 0 = beside the C(t) kernels')
+    ap.add_argument('--late-hist', type=int, default=0, help='grouped schedule: 1 = the histograms of a group run in the tail of its merged fit launch (released by the signal the launch\'s last workgroup writes; the planes of group + 3 batches stay alive), 0 = beside the C(t) kernels')
     ap.add_argument('--no-group-overlap', action='store_true', help='grouped schedule: the next group\'s C(t) kernels wait for the merged fit launch (strict phases)')
     ap.add_argument('--no-permute', action='store_true', help='grouped schedule: dispatch the merged launch in natural residue order')
     ap.add_argument('--dispatch', type=str, default='history', choices=['history', 'random'],
@@ -466,6 +467,8 @@ def main():
         ctx.set_option('ct_fft', args.ct_fft)
     if args.ct_traceless:
         ctx.set_option('ct_traceless', 1)
+    if args.ct_wg_per_cu:
+        ctx.set_option('ct_wg_per_cu', args.ct_wg_per_cu)
     triples = synth.exact_triples(s['R'], s['F'], V)
     pkw = dict(q_rot=q, Diso=synth.DISO, aniso=aniso, field_MHz=(synth.FIELD_MHZ,), zeta=synth.ZETA)
     grouped = args.group > 1 and args.depth > 1 and not args.reserve_cus and not args.aux_cus and not args.hist_on_main

@@ -743,10 +743,14 @@ class GroupedPipeline(DevicePipeline):
                 kernels beside them) -- no fit is in flight, so the C(t) grids have the chip's registers to themselves
                 and the pack / histogram waves find slots beside them;
       phase 2   ONE model-order search over the group's g x V residues (sr_expfit_order_search_batched_f64_dev), one
-                relaxation launch, one pair of copies to pinned memory; with `late_hist` (default) the group's histograms
-                run HERE, in the tail of the merged launch: its last workgroup releases a signal the histogram stream waits
-                for (every residue has a CU by then; only the longest fits are still running and most slots are free), so
-                that phase 1 is C(t) + pack + chunk statistics only.  The planes of group + 3 batches stay alive for that.
+                relaxation launch, one pair of copies to pinned memory; with `late_hist` (an option; the default of rounds 3-4)
+                the group's histograms run HERE, in the tail of the merged launch: its last workgroup releases a signal the
+                histogram stream waits for (every residue has a CU by then; only the longest fits are still running and most
+                slots are free), so that phase 1 is C(t) + pack + chunk statistics only.  The planes of group + 3 batches stay
+                alive for that.  It pays with the pseudo-random dispatch order (2.45 against 2.55 ms per step at 20 steps), whose
+                launch has an idle straggler tail; dispatched longest first (the default) the launch ends with its bulk, the
+                histograms would run behind it with the chip to themselves, and beside the C(t) kernels they cost less: 1.77
+                against 1.82 ms per step at 20 steps, 1.60 against 1.635 in steady state -- hence off by default.
 
     Why: a fit launch lasts as long as its slowest residue (one nine-parameter fit that never converges: ~300 evaluations,
     6.5 ms) while the median residue needs 0.3 ms.  Launched per batch, the stragglers of ~3 batches are always in flight
@@ -773,7 +777,7 @@ class GroupedPipeline(DevicePipeline):
     plane buffers (12 B per frame and vector each; 21 GB for 32 cfg3 batches) + two group buffers (1.7 GB each); checked
     against the free device memory at construction (falls back to late_hist off, see `late_hist_note`)."""
 
-    def __init__(self, ctx, device, frames, V, R, F, dt, group=32, overlap=True, psum_buffers=3, late_hist=True, **kw):
+    def __init__(self, ctx, device, frames, V, R, F, dt, group=32, overlap=True, psum_buffers=3, late_hist=False, **kw):
         kw = dict(kw)
         kw.setdefault('pack_cus', 128)                    # the pack stream on half of the CUs (DevicePipeline.__init__)
         kw['depth'] = max(2, int(psum_buffers))          # the base class's slots: only their raw-sum buffers are used (a rotating pool)

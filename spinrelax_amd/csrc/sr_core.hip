@@ -90,6 +90,7 @@ sr_ctx *sr_create(int device)
     ctx->stream = nullptr;
     ctx->fit_waves = 4;
     ctx->fit_lds = 1;
+    ctx->fit_geo = 1;
     ctx->ct_fft = 3;
     ctx->ct_traceless = 0;
     ctx->fft_table_ready = 0;
@@ -151,6 +152,11 @@ int sr_set_option(sr_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "ct_traceless")) {
         SR_REQUIRE(value == 0 || value == 1, -3, "sr_set_option: ct_traceless must be 0 or 1");
         ctx->ct_traceless = value;
+        return 0;
+    }
+    if (!strcmp(name, "fit_geo")) {
+        SR_REQUIRE(value == 0 || value == 1, -3, "sr_set_option: fit_geo must be 0 or 1");
+        ctx->fit_geo = value;
         return 0;
     }
     if (!strcmp(name, "fit_lds")) {

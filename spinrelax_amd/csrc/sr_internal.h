@@ -19,6 +19,8 @@ struct sr_ctx {
     size_t slot_bytes[SR_NSLOTS];
     // tuning (sr_set_option)
     int fit_waves;      // waves per residue in the model-order search: 1, 2 or 4
+    int fit_geo;        // 1 (default): on a uniform time grid the fit kernels form exp(-t/tau) of a thread's points by multiplication
+                        // (sr_fit.hip, Residue::stage); 0: exp() per point whatever the grid
     int fit_lds;        // 1: stage t, y, 1/sigma of a residue in LDS when it fits; 0: read them from global memory
     int ct_fft;         // kernel 1 when the chunk length allows: 3 (default) = float32 real-input FFT (k_ct_rfft32) for 4096 < F + L <=
                         // 8192, the float64 complex FFT below; 4 = float32 transforms for every 1024 < F + L <= 8192;

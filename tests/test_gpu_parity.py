@@ -581,6 +581,60 @@ def test_device_fit_vs_reference_trials(ctx, tag):
         assert e['worst'] <= w['worst'] * 1.01 + 1e-12, (tag, nP, e, w)
 
 
+def test_fit_uniform_grid_products_and_the_fallback(ctx):
+    """exp(-t/tau) on a uniform time grid: the fit kernels multiply along a thread's points instead of calling exp() per point
+    (option fit_geo, default on; sr_fit.hip Residue::stage decides per residue on the device).  (1) against exp() per point
+    (fit_geo = 0) on the reference's cfg2 / cfg3 trial inputs: the well-conditioned orders (2, 3, 5 parameters) end on the same
+    minimum to what ftol = xtol = 1e-8 leave of it -- chi^2 to the 1e-6 tier of test_device_fit_vs_reference_trials (measured
+    1e-7: the reference's own chi^2 moves as much under a one-ulp change of its input), parameters to 1e-5 of their scale; (2) an axis that is NOT a uniform grid (one time moved by 1e-9
+    of itself; a quadratic axis) takes exp() per point whatever the option says: bit-identical results with fit_geo = 1 and 0;
+    (3) L <= 256 (cfg1: one point per thread) is the exp() path by construction: bit-identical as well."""
+    for tag in ('cfg2', 'cfg3s'):
+        g = golden('%s_fit.npz' % tag)
+        t, y, dy = g['t'], g['y'], g['dy']
+        tau_max = t[0, -1] * 10
+        for j, nP in enumerate(g['listDoG']):
+            if nP > 5:
+                continue
+            p0 = g['trial_p0'][:, j, :nP]
+            out = {}
+            for geo in (1, 0):
+                ctx.set_option('fit_geo', geo)
+                out[geo] = ctx.expfit(t, y, dy, p0, tau_max)
+            ctx.set_option('fit_geo', 1)
+            ok = (out[1][3] > 0) & (out[0][3] > 0)
+            assert np.array_equal(out[1][3] > 0, out[0][3] > 0) and ok.sum() >= 0.75 * len(ok)
+            chi_rel = np.max(np.abs(out[1][2][ok] / out[0][2][ok] - 1.0))
+            scale = np.maximum(np.abs(out[0][0][ok]), 1e-3 * np.max(np.abs(out[0][0][ok]), axis=0))
+            p_rel = np.max(np.abs(out[1][0][ok] - out[0][0][ok]) / scale)
+            print('\n[fit_geo %s, %d parameters] chi^2 %.1e, parameters %.1e' % (tag, nP, chi_rel, p_rel))
+            assert chi_rel < 1e-6 and p_rel < 1e-5, (tag, nP, chi_rel, p_rel)
+    g = golden('cfg2_fit.npz')
+    t, y, dy = g['t'].copy(), g['y'], g['dy']
+    p0 = g['trial_p0'][:, 1, :3]
+    for kind in ('moved', 'quadratic'):
+        t2 = t.copy()
+        if kind == 'moved':
+            t2[:, 300] *= 1.0 + 1e-9
+        else:
+            t2 = t2 * (1.0 + 1e-3 * t2 / t2[:, -1:])
+        res = []
+        for geo in (1, 0):
+            ctx.set_option('fit_geo', geo)
+            res.append(ctx.expfit(t2, y, dy, p0, t2[0, -1] * 10))
+        ctx.set_option('fit_geo', 1)
+        for a, b in zip(res[0], res[1]):
+            assert np.array_equal(a, b, equal_nan=True), kind
+    g = golden('cfg1_fit.npz')
+    res = []
+    for geo in (1, 0):
+        ctx.set_option('fit_geo', geo)
+        res.append(ctx.expfit(g['t'], g['y'], g['dy'], g['trial_p0'][:, 0, :2], g['t'][0, -1] * 10))
+    ctx.set_option('fit_geo', 1)
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_device_fit_failure_modes(ctx):
     """p0 outside the bounds -> scipy raises ValueError, the reference marks the fit failed
     (fitting_Ct_functions.py:325-328); NaN data -> residuals not finite."""

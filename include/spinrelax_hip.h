@@ -50,9 +50,10 @@ sr_ctx      *sr_create(int device);                 /* NULL on failure (see sr_l
 void         sr_destroy(sr_ctx *);
 int          sr_set_stream(sr_ctx *, void *hip_stream);   /* hipStream_t; NULL = default stream  */
 int          sr_sync(sr_ctx *);
-/* Tuning knobs: "fit_waves" = wavefronts per residue in the fits (1, 2 or 4; default 4: with the chip full of fits
- * all three cost the same per residue and 4 has the shortest launch (1.6x and 2.8x shorter than 2 and 1 on the
- * 512-residue benchmark batch); results are bit-identical only between runs with the same value), "fit_lds" = 1/0 keep
+/* Tuning knobs: "fit_waves" = wavefronts per residue in the fits (1, 2 or 4; default 2: four workgroups per CU -- the
+ * model-order search is then limited by its registers alone -- and the shortest time per batch with the chip full, 0.40 ms for the
+ * 512-residue benchmark batch against 0.60 at 4 and 0.82 at 1; a lone launch lasts 6.9 ms at 2, 6.3 at 4, 24.7 at 1; results are
+ * bit-identical only between runs with the same value), "fit_lds" = 1/0 keep
  * a residue's t, C(t), 1/sigma in LDS, "fit_geo" = 1/0 (default 1): when a residue's time axis is a uniform grid (t[l] = t[0] + l dt
  * to 8 ulp -- checked per residue on the device; any other axis always takes exp() per point) the fit kernels form exp(-t/tau) at
  * the points a thread owns by multiplication, exp() once per thread: within 1e-15 of exp() per point, 17 % less time per batch

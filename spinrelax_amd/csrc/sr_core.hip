@@ -88,7 +88,7 @@ sr_ctx *sr_create(int device)
     memset(ctx, 0, sizeof(*ctx));
     ctx->device = device;
     ctx->stream = nullptr;
-    ctx->fit_waves = 4;
+    ctx->fit_waves = 2;
     ctx->fit_lds = 1;
     ctx->fit_geo = 1;
     ctx->ct_fft = 3;

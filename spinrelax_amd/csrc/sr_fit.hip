@@ -521,9 +521,12 @@ constexpr int kRedStride = kNmax * (kNmax + 1) / 2 + kNmax + 2;   // doubles per
 constexpr int kBcast = 16;
 constexpr int kMat = kNmax * (kNmax + 1) / 2;                        // one packed symmetric n x n matrix
 constexpr int kStateDoubles = 16;                                    // SearchState of k_order_search (workgroup-uniform)
+// LDS of a workgroup: reduction scratch, broadcast area, matrices, search state, and -- when the residue is staged -- C(t) and the
+// weights of its L points plus the times of the first W * 64 (one per thread: all the uniform-grid form needs; the paths that need
+// every time read them from global memory).  L = 2048: 37.4 KB at W = 2 (four workgroups per CU), 39.7 KB at W = 4.
 __host__ __device__ constexpr size_t fit_lds_doubles(int W, int64_t L_staged)
 {
-    return (size_t)W * kRedStride + kBcast + (2 + W) * kMat + kStateDoubles + 3 * (size_t)L_staged;
+    return (size_t)W * kRedStride + kBcast + (2 + W) * kMat + kStateDoubles + (L_staged ? (size_t)W * 64 + 2 * (size_t)L_staged : 0);
 }
 
 template <int W, bool LDS>
@@ -551,20 +554,21 @@ struct Residue {
     __device__ __forceinline__ double *matA() const { return fit_smem + MA; }
     __device__ __forceinline__ double *matB() const { return fit_smem + MB; }
     __device__ __forceinline__ double *matLf() const { return fit_smem + LF + (tid >> 6) * kMat; }
-    __device__ __forceinline__ double ld_t(int l) const { return LDS ? fit_smem[RED + l] : tg[l]; }
-    __device__ __forceinline__ double ld_y(int l) const { return LDS ? fit_smem[RED + L + l] : yg[l]; }
-    __device__ __forceinline__ double ld_w(int l) const { return LDS ? fit_smem[RED + 2 * L + l] : wg[l]; }
+    __device__ __forceinline__ double ld_t(int l) const { return tg[l]; }        // any time: global (exp() per point, chi^2)
+    __device__ __forceinline__ double ld_t0() const { return LDS ? fit_smem[RED + tid] : tg[tid < L ? tid : 0]; }   // the thread's first
+    __device__ __forceinline__ double ld_y(int l) const { return LDS ? fit_smem[RED + NTH + l] : yg[l]; }
+    __device__ __forceinline__ double ld_w(int l) const { return LDS ? fit_smem[RED + NTH + L + l] : wg[l]; }
 
     // stage the residue: weights 1/sigma (curve_fit: transform = 1/sigma, _minpack_py.py:985), t, y
     __device__ void stage(const double *t, const double *y, const double *sg_, double *wbuf, int geo_allowed)
     {
         sg = sg_;
+        if (LDS) fit_smem[RED + tid] = t[tid < L ? tid : 0];
         for (int l = tid; l < L; l += NTH) {
             const double w = sg ? 1.0 / sg[l] : 1.0;
             if (LDS) {
-                fit_smem[RED + l] = t[l];
-                fit_smem[RED + L + l] = y[l];
-                fit_smem[RED + 2 * L + l] = w;
+                fit_smem[RED + NTH + l] = y[l];
+                fit_smem[RED + NTH + L + l] = w;
             } else {
                 wbuf[l] = w;
             }
@@ -651,7 +655,7 @@ __device__ __forceinline__ double eval_f(const R &T, const double *x, bool &fini
     auto run = [&](auto GEO) {
         double er[K > 0 ? K : 1], Rk[K > 0 ? K : 1];
         if (GEO) {
-            M::exps(tau_u, rtau, T.ld_t(tid < L ? tid : 0), er);
+            M::exps(tau_u, rtau, T.ld_t0(), er);
             M::exps(tau_u, rtau, T.tstep, Rk);
 #pragma unroll
             for (int k = 0; k < K; ++k) Rk[k] = uni(Rk[k]);
@@ -745,7 +749,7 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
     auto run = [&](auto GEO) {
     double er[K > 0 ? K : 1], Rk[K > 0 ? K : 1], erh[K > 0 ? K : 1], Rh[K > 0 ? K : 1];
     if (GEO) {
-        const double t0 = T.ld_t(tid < L ? tid : 0);
+        const double t0 = T.ld_t0();
         M::exps(tau_u, rtau, t0, er);
         M::exps(tau_u, rtau, T.tstep, Rk);
         if (mode == 0) {
@@ -760,7 +764,9 @@ __device__ __forceinline__ void eval_jac(const R &T, const double *x, const doub
     }
     // one data point: `cached` >= 0 takes the exponentials and the residual at x from the point cache (slot `cached`)
     auto point = [&](int l, int cached) {
-        const double tl = T.ld_t(l), w = T.ld_w(l), yl = T.ld_y(l);
+        const double w = T.ld_w(l), yl = T.ld_y(l);
+        double tl = 0.0;
+        if (!GEO || mode != 0) tl = T.ld_t(l);          // (the uniform-grid form with finite differences never needs the time itself)
         double e[K > 0 ? K : 1], Jr[N], f0;
         if (CACHE && cached >= 0) {
 #pragma unroll

@@ -16,12 +16,12 @@
 // matrix B = (J d)^T (J d) + diag_h is Cholesky-factorised for every Levenberg parameter alpha that
 // More's iteration visits -- phi(alpha) and phi'(alpha) are the same functions, evaluated differently.
 //
-// Mapping: one workgroup of W = 4 waves (one per SIMD of a CU) per residue.  The L data points are spread over the
-// W*64 threads for model evaluation and the J^T J / J^T f reductions (wave shuffles, then a fixed-order
-// combine through LDS); the n <= 11 dimensional algebra is workgroup-uniform, executed redundantly by
-// every thread and held in registers (the kernel is templated on n so every small array is statically
-// indexed).  The critical path of a fit is serial (up to 100 n dependent iterations), so the kernel is
-// latency-bound by design: the W waves exist to shorten each iteration, not to raise throughput.
+// Mapping: one workgroup of W waves per residue (option fit_waves; default 2 since round 5, four workgroups per CU).  The L
+// data points are spread over the W*64 threads for model evaluation and the J^T J / J^T f reductions (wave shuffles, then a
+// fixed-order combine through LDS); the n <= 11 dimensional algebra is workgroup-uniform, run by the leader wave (the kernel
+// is templated on n so every small array is statically indexed).  The critical path of a fit is serial (up to 100 n
+// dependent iterations): more waves per residue shorten an evaluation a little (18.8 us at W = 4, 20.4 at 2) and idle
+// during the leader's algebra; with the chip full W = 2 costs 0.40 ms per 512-residue batch, W = 4 0.60.
 // Floating-point contraction is OFF for this file (spinrelax_amd/build.py): every fused multiply-add is written as
 // fma(), so k_trf<n> and the search_order<n> instances of k_order_search -- separately compiled copies of the same
 // solver -- round identically whatever the optimiser does around them (with -ffp-contract=fast the two differed in
@@ -60,6 +60,12 @@ __device__ __forceinline__ double wsum(double v) { return sr_wave_sum_f64(v); }
 //                            every measure once the reductions below were out of the way (6.69 / 0.728 against 6.84 / 0.746).
 //   SR_FIT_REDUCE_MANY=1 (default) the 54 lane sums of a Jacobian by the register-halving reduction of sr_internal.h
 //                            (different association: the fits move in their last bits): 8.95 -> 6.85 / 0.832 -> 0.745
+//   Round 5, NOT bit-identical (within 1e-15 per exponential; every parity test re-run, per-trial tallies refreshed):
+//   exp(-t/tau) on a uniform time grid by multiplication along a thread's points (Residue::stage, eval_f, eval_jac; option
+//       fit_geo): one exp() per exponential and thread instead of one per point -- 2 instructions per exponential and point
+//       instead of 23: 0.709 -> 0.607 ms saturated, an evaluation of the slowest residue 22.6 -> 18.7 us;
+//   W = 2 and 37 KB of LDS per residue (C(t), weights, one time per thread; the times themselves are only read by the
+//       exp()-per-point paths, from global memory) -> four workgroups per CU: 0.607 -> 0.397 ms saturated.
 // Tried and dropped (bit-identical): evaluating trial points with a fused model + Jacobian pass (an accepted step then needs
 // no second pass: the exponentials of the model once per evaluation instead of twice): 0.716 -> 0.692 ms saturated but
 // 6.58 -> 6.79 ms alone (the slowest residue rejects many trial steps, each now paying for a Jacobian; scratch 872 -> 1 192 B).

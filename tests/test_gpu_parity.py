@@ -635,6 +635,39 @@ def test_fit_uniform_grid_products_and_the_fallback(ctx):
         assert np.array_equal(a, b, equal_nan=True)
 
 
+@pytest.mark.parametrize('W', [1, 2, 4])
+def test_fit_uniform_grid_lengths_and_wave_counts_vs_scipy(ctx, W):
+    """The uniform-grid form at chunk lengths around the thread count (64 W threads per residue: L = 64 W + 1 gives one thread two
+    points and the others one; L not a multiple of it; L below it takes exp() per point), for every wave count, a non-zero time
+    origin, with and without sigma: a clean three-parameter decay with mild noise, fitted from the same start by scipy's
+    curve_fit (what the reference calls, fitting_Ct_functions.py:322) -- parameters to 1e-6, and fit_geo = 0 agrees as well."""
+    from scipy.optimize import curve_fit
+    rng = np.random.RandomState(5 + W)
+    ctx.set_option('fit_waves', W)
+    try:
+        for L in (64 * W - 3, 64 * W + 1, 64 * W * 2 + 37, 1000):
+            for t0, with_sigma in ((0.0, True), (3.5, False)):
+                t = t0 + 2.0 * np.arange(L)
+                tau_true = 0.2 * t[-1]
+                y = 0.85 + 0.15 * np.exp(-t / tau_true) + 1e-4 * rng.standard_normal(L)
+                dy = np.full(L, 1e-3) if with_sigma else None
+                p0 = np.array([[0.5, 0.1 * t[-1], 0.5]])
+                tau_max = 10 * t[-1]
+
+                def model(tt, C, tau, S2):
+                    return S2 + C * np.exp(-tt / tau)
+                ref, _ = curve_fit(model, t, y, sigma=dy, p0=p0[0], bounds=(0, [1.0, tau_max, 1.0]))
+                for geo in (1, 0):
+                    ctx.set_option('fit_geo', geo)
+                    popt, pcov, chi, status, nfev = ctx.expfit(t[None], y[None], None if dy is None else dy[None], p0, tau_max)
+                    assert status[0] > 0
+                    err = np.max(np.abs(popt[0] / ref - 1.0))
+                    assert err < 1e-6, (W, L, t0, with_sigma, geo, popt[0], ref)
+    finally:
+        ctx.set_option('fit_geo', 1)
+        ctx.set_option('fit_waves', 2)
+
+
 def test_device_fit_failure_modes(ctx):
     """p0 outside the bounds -> scipy raises ValueError, the reference marks the fit failed
     (fitting_Ct_functions.py:325-328); NaN data -> residuals not finite."""

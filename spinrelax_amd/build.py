@@ -59,6 +59,7 @@ def build(force=False, verbose=True):
     objs = []
     bid = build_id()
     idfile = os.path.join(CSRC, '.build_id')
+    jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         if not os.path.isfile(s):
@@ -73,12 +74,24 @@ def build(force=False, verbose=True):
         stamp = o + '.cmd'
         sig = ' '.join(FLAGS + extra + [src])                  # no absolute paths: the tree is copied to the GPU box as it is
         if force or _stale(o, [s] + hdrs) or not _same_flags(stamp, sig):
-            if verbose:
-                print(' '.join(cmd), flush=True)
-            subprocess.check_call(cmd)
-            with open(stamp, 'w') as fp:
-                fp.write(sig)
+            jobs.append((src, cmd, stamp, sig))
         objs.append(o)
+
+    def compile_one(job):
+        src, cmd, stamp, sig = job
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(stamp, 'w') as fp:
+            fp.write(sig)
+
+    if jobs:
+        # the sources compile side by side (sr_fit.hip alone takes minutes: the longest first); at most four at a time, each
+        # hipcc is one process of ~2 GB
+        from concurrent.futures import ThreadPoolExecutor
+        jobs.sort(key=lambda j: 0 if j[0] == 'sr_fit.hip' else 1)
+        with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
+            list(pool.map(compile_one, jobs))
     with open(idfile, 'w') as fp:
         fp.write(bid + '\n')
     if force or _stale(LIB, objs):

@@ -986,8 +986,11 @@ def main():
                        'vectors_total': Vtot, 'vectors_per_gpu': V, 'exact_triples_per_gpu': triples, 'exact_triples_total': triples_total,
                        'sharding': 'contiguous vector ranges (spinrelax_amd/dist.py:shard_range; no data-path collective; all-gather of results)',
                        'schedule': ('grouped: pack / C(t) / chunk statistics%s of %d batches back to back, then ONE merged model-order search + '
-                                    'relaxation launch over their %d residues (dispatched in a fixed pseudo-random order)%s; next group%s'
+                                    'relaxation launch over their %d residues (dispatched %s)%s; next group%s'
                                     % ('' if late_hist_used else ' / histogram', group_used, group_used * V,
+                                       'in natural order' if args.no_permute else
+                                       ('longest first by the evaluation counts of the last collected batch' if args.dispatch == 'history'
+                                        else 'in a fixed pseudo-random order'),
                                        ', their histograms in the tail of that launch (released by a signal its last workgroup writes)' if late_hist_used else '',
                                        ' overlaps it' if not args.no_group_overlap else ' waits for it'))
                                    if grouped else 'per batch: every batch launches its own fits, %d batches in flight' % depth_used,

@@ -942,7 +942,7 @@ def main():
                                               'note': 'sum over the kernels of a batch of the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE: requests the L2s send to the '
                                                       'fabric, Infinity-Cache hits included) against vectors in once + C(t), dC(t), histogram out; not measured in this run. '
                                                       'The pack writes the planes once and they are read by kernel 1 and kernel 2 (1.84 GB of it); k_ct_rfft32 re-reads its '
-                                                      'planes per pass and, at four workgroups per CU, 128 x 48 KB per XCD exceed its 4 MB L2: 1.7 GB of re-reads come from the '
+                                                      'planes per pass and, at four workgroups per CU, 128 x 48 KB per XCD exceed its 4 MB L2: 0.9 GB of re-reads come from the '
                                                       'Infinity Cache (DESIGN.md section 4)%s' % stale_txt}
         roofline['fp64_issue_probe'] = probe
         roofline['frac_alone'] = tk.get('frac_alone')

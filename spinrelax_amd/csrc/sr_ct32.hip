@@ -478,6 +478,13 @@ SR_PK c32 f32_sig5(c32 x, c32 y, c32 z, float m) { return pk_fma(z, z, pk_fma(x,
 #ifndef SR_CT32_PF
 #define SR_CT32_PF 0
 #endif
+#ifndef SR_CT32_NT
+#define SR_CT32_NT 2           // cache policy (aux bits of the buffer loads: 2 = nt) of the plane loads whose next use is two or more
+                              // passes away -- z in the prologue, y of signal 2, x of signal 3, everything in the epilogue.  The planes a
+                              // pass re-reads do not fit the L2 of an XCD at four workgroups per CU (128 x 48 KB); with the far reuses
+                              // out of the way the near ones hit: 2.30 -> 1.53 GB fetched per launch (PMC, 0 = every load temporal),
+                              // same duration alone and in the pipeline
+#endif
 #ifndef SR_CT32_WAVES16
 #define SR_CT32_WAVES16 3        // the same for the N1 = 16 kernel (M = 8192: 16 input blocks): 146 VGPRs, no scratch, three workgroups per CU
 #endif
@@ -512,19 +519,21 @@ __global__ __launch_bounds__(256, (N1 == 16 ? SR_CT32_WAVES16 : SR_CT32_WAVES)) 
     const bool even = FULL || ((start | a.Npad | (int64_t)F) & 1) == 0;   // frames 2m, 2m + 1 of every plane share an aligned 8 bytes
 
     // buffer resources that cover exactly the chunk's F frames of a plane: a frame past the chunk reads as 0
-#define SR_F32_LOAD1(DST, PLANE, T) SR_F32_LOADR(DST, PLANE, T, 0, NZ)
-#define SR_F32_LOADR(DST, PLANE, T, LO, HI)                                                      \
+#define SR_F32_LOAD1(DST, PLANE, T) SR_F32_LOADP(DST, PLANE, T, 0, NZ, 0)
+#define SR_F32_LOADR(DST, PLANE, T, LO, HI) SR_F32_LOADP(DST, PLANE, T, LO, HI, 0)
+#define SR_F32_LOAD1NT(DST, PLANE, T) SR_F32_LOADP(DST, PLANE, T, 0, NZ, SR_CT32_NT)
+#define SR_F32_LOADP(DST, PLANE, T, LO, HI, POL)                                                 \
     {                                                                                            \
         const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                    \
             const_cast<float *>(px + (int64_t)__builtin_amdgcn_readfirstlane(PLANE) * a.Npad), (short)0, F * 4, 0x00020000); \
         if (even) {                                                                              \
             _Pragma("unroll") for (int n1 = (LO); n1 < (HI); ++n1)                              \
-                DST[n1] = __builtin_bit_cast(c32, __builtin_amdgcn_raw_buffer_load_b64(rs_, 8 * ((T) + 256 * n1), 0, 0)); \
+                DST[n1] = __builtin_bit_cast(c32, __builtin_amdgcn_raw_buffer_load_b64(rs_, 8 * ((T) + 256 * n1), 0, (POL))); \
         } else {                                                                                 \
             _Pragma("unroll") for (int n1 = (LO); n1 < (HI); ++n1) {                            \
                 const int ob_ = 8 * ((T) + 256 * n1);                                            \
-                DST[n1] = c32{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, ob_, 0, 0)),               \
-                              __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, ob_ + 4, 0, 0))};          \
+                DST[n1] = c32{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, ob_, 0, (POL))),           \
+                              __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, ob_ + 4, 0, (POL)))};      \
             }                                                                                    \
         }                                                                                        \
     }
@@ -552,7 +561,7 @@ __global__ __launch_bounds__(256, (N1 == 16 ? SR_CT32_WAVES16 : SR_CT32_WAVES)) 
         c32 xr[NZ], yr[NZ], zr[NZ];
         SR_F32_LOAD1(xr, 0, tid0)
         SR_F32_LOAD1(yr, 1, tid0)
-        SR_F32_LOAD1(zr, 2, tid0)
+        SR_F32_LOAD1NT(zr, 2, tid0)
         c32 s0 = {0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0, s4 = s0, s5 = s0;
         float emax = 0.f;
 #pragma unroll
@@ -684,8 +693,18 @@ __global__ __launch_bounds__(256, (N1 == 16 ? SR_CT32_WAVES16 : SR_CT32_WAVES)) 
                 constexpr int GE = 8 < NZ ? 8 : NZ;         // blocks per group
                 if (g0 > 0) asm volatile("" ::: "memory");
                 if (SR_CT32_PF == 0 || g0 > 0) {
-                    SR_F32_LOADR(ar, f32_plane_a(cn), tid, g0, g0 + GE)
-                    SR_F32_LOADR(br, f32_plane_b(cn), tid, g0, g0 + GE)
+                    // cache policy by the distance to the plane's next use (SR_CT32_NT): y of signal 2 (next: signal 4) and x of
+                    // signal 3 (next: the epilogue) are not wanted again for two passes
+                    if (SR_CT32_NT != 0 && cn == 3) {
+                        SR_F32_LOADP(ar, 0, tid, g0, g0 + GE, SR_CT32_NT)
+                    } else {
+                        SR_F32_LOADR(ar, f32_plane_a(cn), tid, g0, g0 + GE)
+                    }
+                    if (SR_CT32_NT != 0 && cn == 2) {
+                        SR_F32_LOADP(br, 1, tid, g0, g0 + GE, SR_CT32_NT)
+                    } else {
+                        SR_F32_LOADR(br, f32_plane_b(cn), tid, g0, g0 + GE)
+                    }
                 }
                 if (cn == 1) {                                     // x^2 - y^2
 #pragma unroll
@@ -759,9 +778,9 @@ __global__ __launch_bounds__(256, (N1 == 16 ? SR_CT32_WAVES16 : SR_CT32_WAVES)) 
     double *tot = reinterpret_cast<double *>(aux);       // wave totals (the float sums of the prologue are dead)
     {
         c32 xr[NZ], yr[NZ], zr[NZ];
-        SR_F32_LOAD1(xr, 0, tid)
-        SR_F32_LOAD1(yr, 1, tid)
-        SR_F32_LOAD1(zr, 2, tid)
+        SR_F32_LOAD1NT(xr, 0, tid)
+        SR_F32_LOAD1NT(yr, 1, tid)
+        SR_F32_LOAD1NT(zr, 2, tid)
         float mm[6], wm[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -844,7 +863,9 @@ __global__ __launch_bounds__(256, (N1 == 16 ? SR_CT32_WAVES16 : SR_CT32_WAVES)) 
     }
 #endif
 #undef SR_F32_LOAD1
+#undef SR_F32_LOAD1NT
 #undef SR_F32_LOADR
+#undef SR_F32_LOADP
 #undef SR_F32_MASK
 }
 
